@@ -1,0 +1,238 @@
+"""ctypes binding of libflowdn.so (include/flowdn.h).
+
+There is no CPU fallback: if the HIP library is missing or a GPU call fails, this raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflowdn.so")
+
+USE_INITIAL_FLOW = 4
+BORDER_MEAN_PAD = 0
+BORDER_WRAP = 1
+TIMER_NAMES = ("polyexp", "flow", "warp", "permute", "transfer")
+
+
+class FlowdnError(RuntimeError):
+    pass
+
+
+class SweepParams(ctypes.Structure):
+    """struct fdn_sweep_params"""
+    _fields_ = [("levels", ctypes.c_int), ("winsize", ctypes.c_int), ("iters", ctypes.c_int),
+                ("poly_n", ctypes.c_int), ("poly_sigma", ctypes.c_double),
+                ("border_mode", ctypes.c_int), ("chained", ctypes.c_int), ("use_of", ctypes.c_int)]
+
+
+# every symbol include/flowdn.h declares (tests check the .so exports all of them)
+EXPORTS = [
+    "fdn_create", "fdn_destroy", "fdn_last_error", "fdn_set_stream", "fdn_synchronize",
+    "fdn_set_workspace_limit", "fdn_malloc", "fdn_free", "fdn_memcpy_h2d", "fdn_memcpy_d2h",
+    "fdn_memset_f32", "fdn_gaussian_kernel", "fdn_farneback", "fdn_warp",
+    "fdn_filter_axis_dev", "fdn_filter_axis", "fdn_filter_3d_dev", "fdn_filter_3d",
+    "fdn_mean_dev", "fdn_sum_dev", "fdn_sweep_stack_dev", "fdn_permute_dev",
+    "fdn_enable_timers", "fdn_get_timers", "fdn_version",
+]
+
+_lib = None
+
+
+def load():
+    """Load libflowdn.so; raises FlowdnError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FlowdnError(
+            f"{LIB_PATH} not found: build it with `make -C flowdenoising_amd/csrc` "
+            "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.fdn_last_error.restype = ctypes.c_char_p
+    lib.fdn_version.restype = ctypes.c_char_p
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("fdn_last_error", "fdn_version"):
+            fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc < 0:
+        raise FlowdnError(load().fdn_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def gaussian_kernel(sigma):
+    """fdn_gaussian_kernel: host-only, needs no GPU."""
+    lib = load()
+    out = np.empty(4096, dtype=np.float64)
+    K = lib.fdn_gaussian_kernel(ctypes.c_double(float(sigma)), _ptr(out), ctypes.c_int(out.size))
+    if K <= 0:
+        raise FlowdnError(lib.fdn_last_error().decode() or f"kernel too long ({-K})")
+    return out[:K].copy()
+
+
+class Handle:
+    """One fdn_handle: a GPU, its stream and the library-owned scratch."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        check(self._lib.fdn_create(ctypes.c_int(device), ctypes.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            self._lib.fdn_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing ------------------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        check(self._lib.fdn_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self):
+        check(self._lib.fdn_synchronize(self._h))
+
+    def set_workspace_limit(self, nbytes):
+        check(self._lib.fdn_set_workspace_limit(self._h, ctypes.c_size_t(int(nbytes))))
+
+    def malloc(self, nbytes):
+        p = ctypes.c_void_p()
+        check(self._lib.fdn_malloc(self._h, ctypes.c_size_t(int(nbytes)), ctypes.byref(p)))
+        return p.value
+
+    def free(self, dptr):
+        check(self._lib.fdn_free(self._h, ctypes.c_void_p(dptr)))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        check(self._lib.fdn_memcpy_h2d(self._h, ctypes.c_void_p(dptr), _ptr(arr), ctypes.c_size_t(arr.nbytes)))
+
+    def d2h(self, arr, dptr):
+        assert arr.flags["C_CONTIGUOUS"]
+        check(self._lib.fdn_memcpy_d2h(self._h, _ptr(arr), ctypes.c_void_p(dptr), ctypes.c_size_t(arr.nbytes)))
+
+    def enable_timers(self, on=True):
+        check(self._lib.fdn_enable_timers(self._h, ctypes.c_int(int(on))))
+
+    def timers(self, reset=False):
+        out = (ctypes.c_double * len(TIMER_NAMES))()
+        check(self._lib.fdn_get_timers(self._h, out, ctypes.c_int(int(reset))))
+        return dict(zip(TIMER_NAMES, list(out)))
+
+    # -- pair operators ------------------------------------------------------------
+    def farneback(self, prev, next, flow, levels, winsize, iters, poly_n, poly_sigma, flags):
+        prev = np.ascontiguousarray(prev, dtype=np.float32)
+        next = np.ascontiguousarray(next, dtype=np.float32)
+        H, W = prev.shape
+        if next.shape != (H, W):
+            raise ValueError("prev and next must have the same shape")
+        if flags & USE_INITIAL_FLOW:
+            if flow is None or flow.shape != (H, W, 2) or flow.dtype != np.float32 or not flow.flags["C_CONTIGUOUS"]:
+                raise ValueError("USE_INITIAL_FLOW needs a contiguous (H, W, 2) float32 flow")
+        else:
+            flow = np.zeros((H, W, 2), dtype=np.float32)
+        check(self._lib.fdn_farneback(self._h, _ptr(prev), _ptr(next), _ptr(flow), ctypes.c_int(H), ctypes.c_int(W),
+                                      ctypes.c_int(int(levels)), ctypes.c_int(int(winsize)), ctypes.c_int(int(iters)),
+                                      ctypes.c_int(int(poly_n)), ctypes.c_double(float(poly_sigma)),
+                                      ctypes.c_int(int(flags))))
+        return flow
+
+    def warp(self, reference, flow):
+        reference = np.ascontiguousarray(reference, dtype=np.float32)
+        flow = np.ascontiguousarray(flow, dtype=np.float32)
+        H, W = flow.shape[:2]
+        if reference.shape != (H, W) or flow.shape != (H, W, 2):
+            raise ValueError("reference (H, W) and flow (H, W, 2) shapes disagree")
+        dst = np.empty((H, W), dtype=np.float32)
+        check(self._lib.fdn_warp(self._h, _ptr(reference), _ptr(flow), _ptr(dst), ctypes.c_int(H), ctypes.c_int(W)))
+        return dst
+
+    # -- volume operators ----------------------------------------------------------
+    @staticmethod
+    def _kernels(kernels):
+        keep = []
+        ptrs = (ctypes.c_void_p * 3)()
+        Ks = (ctypes.c_int * 3)()
+        for a in range(3):
+            k = kernels[a]
+            if k is None:
+                ptrs[a] = None
+                Ks[a] = 0
+            else:
+                k = np.ascontiguousarray(k, dtype=np.float64)
+                keep.append(k)
+                ptrs[a] = k.ctypes.data
+                Ks[a] = k.size
+        return ptrs, Ks, keep
+
+    def filter_axis(self, vol, axis, kernel, pad_value, params):
+        vol = np.ascontiguousarray(vol, dtype=np.float32)
+        Z, Y, X = vol.shape
+        kernel = np.ascontiguousarray(kernel, dtype=np.float64)
+        out = np.empty_like(vol)
+        check(self._lib.fdn_filter_axis(self._h, _ptr(vol), _ptr(out), ctypes.c_int(Z), ctypes.c_int(Y), ctypes.c_int(X),
+                                        ctypes.c_int(axis), _ptr(kernel), ctypes.c_int(kernel.size),
+                                        ctypes.c_float(float(pad_value)), ctypes.byref(params)))
+        return out
+
+    def filter_3d(self, vol, kernels, pad_value, params):
+        vol = np.ascontiguousarray(vol, dtype=np.float32)
+        Z, Y, X = vol.shape
+        ptrs, Ks, keep = self._kernels(kernels)
+        out = np.empty_like(vol)
+        check(self._lib.fdn_filter_3d(self._h, _ptr(vol), _ptr(out), ctypes.c_int(Z), ctypes.c_int(Y), ctypes.c_int(X),
+                                      ptrs, Ks, ctypes.c_float(float(pad_value)), ctypes.byref(params)))
+        return out
+
+    def filter_3d_dev(self, d_in, d_out, shape, kernels, pad_value, params):
+        Z, Y, X = shape
+        ptrs, Ks, keep = self._kernels(kernels)
+        check(self._lib.fdn_filter_3d_dev(self._h, ctypes.c_void_p(d_in), ctypes.c_void_p(d_out), ctypes.c_int(Z),
+                                          ctypes.c_int(Y), ctypes.c_int(X), ptrs, Ks,
+                                          ctypes.c_float(float(pad_value)), ctypes.byref(params)))
+
+    def filter_axis_dev(self, d_in, d_out, shape, axis, kernel, pad_value, params):
+        Z, Y, X = shape
+        kernel = np.ascontiguousarray(kernel, dtype=np.float64)
+        check(self._lib.fdn_filter_axis_dev(self._h, ctypes.c_void_p(d_in), ctypes.c_void_p(d_out), ctypes.c_int(Z),
+                                            ctypes.c_int(Y), ctypes.c_int(X), ctypes.c_int(axis), _ptr(kernel),
+                                            ctypes.c_int(kernel.size), ctypes.c_float(float(pad_value)),
+                                            ctypes.byref(params)))
+
+    def sweep_stack_dev(self, d_stack, d_out, S, H, W, kernel, params):
+        kernel = np.ascontiguousarray(kernel, dtype=np.float64)
+        check(self._lib.fdn_sweep_stack_dev(self._h, ctypes.c_void_p(d_stack), ctypes.c_void_p(d_out), ctypes.c_int(S),
+                                            ctypes.c_int(H), ctypes.c_int(W), _ptr(kernel), ctypes.c_int(kernel.size),
+                                            ctypes.byref(params)))
+
+    def permute_dev(self, d_in, d_out, dims, strides):
+        A, B, C = dims
+        sa, sb, sc = strides
+        check(self._lib.fdn_permute_dev(self._h, ctypes.c_void_p(d_in), ctypes.c_void_p(d_out), ctypes.c_int(A),
+                                        ctypes.c_int(B), ctypes.c_int(C), ctypes.c_int64(sa), ctypes.c_int64(sb),
+                                        ctypes.c_int64(sc)))
+
+    def mean_dev(self, d_in, count):
+        m = ctypes.c_float()
+        check(self._lib.fdn_mean_dev(self._h, ctypes.c_void_p(d_in), ctypes.c_size_t(int(count)), ctypes.byref(m)))
+        return np.float32(m.value)
+
+    def sum_dev(self, d_in, count):
+        s = ctypes.c_double()
+        check(self._lib.fdn_sum_dev(self._h, ctypes.c_void_p(d_in), ctypes.c_size_t(int(count)), ctypes.byref(s)))
+        return s.value

@@ -1,0 +1,660 @@
+// fdn_api.hip -- C ABI (include/flowdn.h) over the gfx950 kernels: handle, scratch
+// memory, the sweep driver that batches the Farneback chain over all target slices, and
+// the host-pointer convenience entry points.
+#include "../../include/flowdn.h"
+#include "fdn_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+namespace fdn {
+
+static thread_local std::string g_err;
+
+static int fail(const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+
+#define FDN_HIP(expr)                                                                   \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// ---- host-side constants ----------------------------------------------------------
+// FarnebackPrepareGaussian (OpenCV optflowgf.cpp), reached from seq:62 with
+// poly_n = 5, poly_sigma = 1.2.  The 6x6 Gram matrix of (1,x,y,x^2,y^2,xy) under the
+// separable weight has only four distinct moments; its inverse entries are taken in
+// closed form from the (1,x^2,y^2) 3x3 block.
+void prepare_poly_consts(int n, double sigma, PolyConsts* pc)
+{
+    if (sigma < 1.1920928955078125e-07) sigma = n * 0.3;
+    std::vector<float> gb(2 * n + 1), xgb(2 * n + 1), xxgb(2 * n + 1);
+    float* g = gb.data() + n; float* xg = xgb.data() + n; float* xxg = xxgb.data() + n;
+    double s = 0.;
+    for (int x = -n; x <= n; x++) {
+        g[x] = (float)exp(-x * x / (2 * sigma * sigma));
+        s += g[x];
+    }
+    s = 1. / s;
+    for (int x = -n; x <= n; x++) {
+        g[x] = (float)(g[x] * s);
+        xg[x] = (float)(x * g[x]);
+        xxg[x] = (float)(x * x * g[x]);
+    }
+    double a = 0, b = 0, c = 0, d = 0; // G(0,0), G(1,1), G(3,3), G(5,5)
+    for (int y = -n; y <= n; y++)
+        for (int x = -n; x <= n; x++) {
+            a += g[y] * g[x];
+            b += g[y] * g[x] * x * x;
+            c += g[y] * g[x] * x * x * x * x;
+            d += g[y] * g[x] * x * x * y * y;
+        }
+    double q = a * (c + d) - 2 * b * b;
+    pc->n = n;
+    pc->ig11 = 1. / b;
+    pc->ig55 = 1. / d;
+    pc->ig03 = -b / q;
+    pc->ig33 = (a * c - b * b) / ((c - d) * q);
+    for (int k = 0; k <= n; k++) { pc->g[k] = g[k]; pc->xg[k] = xg[k]; pc->xxg[k] = xxg[k]; }
+}
+
+// cv::getGaussianKernel(n, sigma, CV_32F)
+void prepare_blur_taps(int n, double sigma, BlurTaps* bt)
+{
+    bt->n = n;
+    if (sigma <= 0 && (n == 1 || n == 3 || n == 5 || n == 7)) {
+        static const float t1[] = {1.f};
+        static const float t3[] = {0.25f, 0.5f, 0.25f};
+        static const float t5[] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+        static const float t7[] = {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f};
+        const float* t = n == 1 ? t1 : n == 3 ? t3 : n == 5 ? t5 : t7;
+        for (int i = 0; i < n; i++) bt->k[i] = t[i];
+        return;
+    }
+    double sigmaX = sigma > 0 ? sigma : n * 0.15 + 0.35;
+    double scale2X = -0.125 / (sigmaX * sigmaX);
+    int n2 = (n - 1) / 2;
+    std::vector<double> vals(n2 + 1);
+    double sum = 0;
+    for (int i = 0, x = 1 - n; i < n2; i++, x += 2) {
+        vals[i] = exp((double)(x * x) * scale2X);
+        sum += vals[i];
+    }
+    sum *= 2.0;
+    sum += 1.0;
+    if ((n & 1) == 0) sum += 1.0;
+    double mul1 = 1.0 / sum;
+    for (int i = 0; i < n2; i++) bt->k[i] = bt->k[n - 1 - i] = (float)(vals[i] * mul1);
+    bt->k[n2] = (float)mul1;
+    if ((n & 1) == 0) bt->k[n2 + 1] = (float)mul1;
+}
+
+} // namespace fdn
+
+using namespace fdn;
+
+// ---- handle -----------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct fdn_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    size_t ws_limit = 0;
+    DevBuf R, M0, M1, flow, stack, sweep_out, vol_a, vol_b, partials, pair;
+    bool timers = false;
+    double tms[FDN_TIMER_COUNT] = {0, 0, 0, 0, 0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static int ensure(fdn_ctx* h, DevBuf& b, size_t bytes)
+{
+    if (b.cap >= bytes) return 0;
+    if (b.p) {
+        FDN_HIP(hipStreamSynchronize(h->stream));
+        FDN_HIP(hipFree(b.p));
+        b.p = nullptr; b.cap = 0;
+    }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) { b.p = nullptr; return fail("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
+    b.cap = bytes;
+    return 0;
+}
+
+struct ScopedTimer {
+    fdn_ctx* h; int which;
+    ScopedTimer(fdn_ctx* h_, int w) : h(h_), which(w) { if (h->timers) (void)hipEventRecord(h->ev0, h->stream); }
+    ~ScopedTimer()
+    {
+        if (!h->timers) return;
+        (void)hipEventRecord(h->ev1, h->stream);
+        (void)hipEventSynchronize(h->ev1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+        h->tms[which] += ms;
+    }
+};
+
+static int check_params(const fdn_sweep_params* p, int K)
+{
+    if (!p) return fail("params is NULL");
+    if (K < 1 || (K & 1) == 0) return fail("kernel.size must be odd (seq:93), got %d", K);
+    if (p->use_of) {
+        if (p->winsize < 1) return fail("winsize must be >= 1, got %d", p->winsize);
+        if (p->poly_n < 1 || p->poly_n > 7) return fail("poly_n must be in 1..7, got %d", p->poly_n);
+        if (p->iters < 0) return fail("iters must be >= 0");
+        if (p->levels < 0) return fail("levels must be >= 0");
+    }
+    return 0;
+}
+
+// number of pyramid levels OpenCV actually uses (calc(): min_size = 32)
+static int effective_levels(int levels, int H, int W)
+{
+    int k = 0;
+    double scale = 1;
+    for (; k < levels; k++) {
+        scale *= 0.5;
+        if (W * scale < 32 || H * scale < 32) break;
+    }
+    return k;
+}
+
+// Farneback level-0 iterations for a batch of pairs whose R planes are in Rstack and whose
+// flows (initial -> final) are in `flow`; M0/M1 are ping-pong scratch for npairs.
+static void run_iterations(fdn_ctx* h, const float* Rstack, float* flow, float* M0, float* M1, PairBatch pb,
+                           int H, int W, int winsize, int iters)
+{
+    launch_update_matrices(Rstack, flow, M0, pb, H, W, h->stream);
+    float* cur = M0; float* nxt = M1;
+    for (int it = 0; it < iters; it++) {
+        bool update = it < iters - 1;
+        launch_update_flow(Rstack, cur, update ? nxt : nullptr, flow, pb, H, W, winsize, h->stream);
+        std::swap(cur, nxt);
+    }
+}
+
+static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H, int W, const double* kernel, int K,
+                       const fdn_sweep_params* p)
+{
+    if (check_params(p, K)) return -1;
+    if (S <= 0 || H <= 0 || W <= 0) return fail("bad stack dims S=%d H=%d W=%d", S, H, W);
+    const int r = K / 2;
+    const size_t HW = (size_t)H * W;
+    hipStream_t st = h->stream;
+
+    if (!p->use_of) { // seq:184-185: taps in index order
+        ScopedTimer t(h, FDN_TIMER_WARP);
+        launch_fill(out, 0.f, (size_t)S * HW, st);
+        for (int i = 0; i < K; i++) launch_axpy_slices(stack, out, PairBatch{S, r, i - r}, H, W, kernel[i], st);
+        FDN_HIP(hipGetLastError());
+        return 0;
+    }
+    if (effective_levels(p->levels, H, W) > 0)
+        return fail("levels > 0 on %dx%d images needs the pyramid path, which this build does not have yet", W, H);
+
+    const int nstack = S + 2 * r;
+    if (ensure(h, h->R, (size_t)nstack * 5 * HW * sizeof(float))) return -1;
+    PolyConsts pc;
+    prepare_poly_consts(p->poly_n, p->poly_sigma, &pc);
+    {
+        ScopedTimer t(h, FDN_TIMER_POLYEXP);
+        launch_blur3_polyexp(stack, (float*)h->R.p, nstack, H, W, pc, st);
+    }
+    // targets per batch, bounded by the workspace limit: flow 8 B + two M sets 40 B per pixel
+    size_t per_target = HW * (8 + 40);
+    size_t budget = h->ws_limit;
+    if (!budget) {
+        size_t fre = 0, tot = 0;
+        FDN_HIP(hipMemGetInfo(&fre, &tot));
+        size_t have = h->flow.cap + h->M0.cap + h->M1.cap;
+        budget = (fre + have) / 10 * 8;
+    }
+    int C = (int)std::min<size_t>((size_t)S, std::max<size_t>(1, budget / per_target));
+    if (ensure(h, h->flow, (size_t)C * HW * 8)) return -1;
+    if (ensure(h, h->M0, (size_t)C * HW * 20)) return -1;
+    if (ensure(h, h->M1, (size_t)C * HW * 20)) return -1;
+    float* R = (float*)h->R.p; float* flow = (float*)h->flow.p;
+    float* M0 = (float*)h->M0.p; float* M1 = (float*)h->M1.p;
+
+    for (int c0 = 0; c0 < S; c0 += C) {
+        int n = std::min(C, S - c0);
+        float* acc = out + (size_t)c0 * HW;
+        launch_fill(acc, 0.f, (size_t)n * HW, st);
+        for (int side = 0; side < 2; side++) {
+            if (side == 1) launch_axpy_slices(stack, acc, PairBatch{n, r + c0, 0}, H, W, kernel[r], st); // seq:108
+            launch_fill(flow, 0.f, (size_t)n * HW * 2, st);                                              // seq:94,109
+            for (int step = 0; step < r; step++) {
+                int d = side == 0 ? -(step + 1) : (step + 1); // nearest neighbour first (seq:95,110)
+                PairBatch pb{n, r + c0, d};
+                if (!p->chained && step > 0) launch_fill(flow, 0.f, (size_t)n * HW * 2, st);
+                {
+                    ScopedTimer t(h, FDN_TIMER_FLOW);
+                    run_iterations(h, R, flow, M0, M1, pb, H, W, p->winsize, p->iters);
+                }
+                {
+                    ScopedTimer t(h, FDN_TIMER_WARP);
+                    launch_warp_accumulate(stack, flow, acc, pb, H, W, kernel[r + d], st);
+                }
+            }
+        }
+    }
+    FDN_HIP(hipGetLastError());
+    return 0;
+}
+
+// stack[r + s] = slice s of `in` along `axis`, re-oriented so that slices are outermost and
+// images keep the reference's (rows, cols): Z: (Y,X); Y: (Z,X) (seq:255); X: (Z,Y) (seq:333).
+static void axis_dims(int Z, int Y, int X, int axis, int* S, int* H, int* W)
+{
+    if (axis == 0) { *S = Z; *H = Y; *W = X; }
+    else if (axis == 1) { *S = Y; *H = Z; *W = X; }
+    else { *S = X; *H = Z; *W = Y; }
+}
+
+static int filter_axis_dev(fdn_ctx* h, const float* d_in, float* d_out, int Z, int Y, int X, int axis,
+                           const double* kernel, int K, float pad_value, const fdn_sweep_params* p)
+{
+    if (check_params(p, K)) return -1;
+    if (axis < 0 || axis > 2) return fail("axis must be 0, 1 or 2");
+    if (Z <= 0 || Y <= 0 || X <= 0) return fail("bad volume dims");
+    if (d_in == d_out) return fail("in and out must not alias");
+    int S, H, W;
+    axis_dims(Z, Y, X, axis, &S, &H, &W);
+    const int r = K / 2;
+    const size_t HW = (size_t)H * W;
+    hipStream_t st = h->stream;
+    if (ensure(h, h->stack, (size_t)(S + 2 * r) * HW * sizeof(float))) return -1;
+    float* stack = (float*)h->stack.p;
+    float* interior = stack + (size_t)r * HW;
+    {
+        ScopedTimer t(h, FDN_TIMER_PERMUTE);
+        if (axis == 0) FDN_HIP(hipMemcpyAsync(interior, d_in, (size_t)S * HW * sizeof(float), hipMemcpyDeviceToDevice, st));
+        else if (axis == 1) launch_permute(d_in, interior, Y, Z, X, X, (int64_t)Y * X, 1, st);
+        else launch_permute(d_in, interior, X, Z, Y, 1, (int64_t)Y * X, X, st);
+        if (p->border_mode == FDN_BORDER_WRAP) {
+            for (int q = 0; q < r; q++) { // par:312: (s + i - ks2) % n
+                int lo = ((q - r) % S + S) % S, hi = (S + q) % S;
+                FDN_HIP(hipMemcpyAsync(stack + (size_t)q * HW, interior + (size_t)lo * HW, HW * sizeof(float), hipMemcpyDeviceToDevice, st));
+                FDN_HIP(hipMemcpyAsync(stack + (size_t)(r + S + q) * HW, interior + (size_t)hi * HW, HW * sizeof(float), hipMemcpyDeviceToDevice, st));
+            }
+        } else { // seq:88-89
+            launch_fill(stack, pad_value, (size_t)r * HW, st);
+            launch_fill(stack + (size_t)(r + S) * HW, pad_value, (size_t)r * HW, st);
+        }
+    }
+    float* sw_out = d_out;
+    if (axis != 0) {
+        if (ensure(h, h->sweep_out, (size_t)S * HW * sizeof(float))) return -1;
+        sw_out = (float*)h->sweep_out.p;
+    }
+    if (sweep_stack(h, stack, sw_out, S, H, W, kernel, K, p)) return -1;
+    if (axis != 0) {
+        ScopedTimer t(h, FDN_TIMER_PERMUTE);
+        if (axis == 1) launch_permute(sw_out, d_out, Z, Y, X, X, (int64_t)Z * X, 1, st);      // out[z][y][x] = t[y][z][x]
+        else launch_permute(sw_out, d_out, Z, Y, X, Y, 1, (int64_t)Z * Y, st);                // out[z][y][x] = t[x][z][y]
+    }
+    FDN_HIP(hipGetLastError());
+    return 0;
+}
+
+static int filter_3d_dev(fdn_ctx* h, const float* d_in, float* d_out, int Z, int Y, int X,
+                         const double* const kernels[3], const int K[3], float pad_value, const fdn_sweep_params* p)
+{
+    if (!kernels || !K) return fail("kernels/K is NULL");
+    int axes[3], na = 0;
+    for (int a = 0; a < 3; a++) if (kernels[a] && K[a] > 0) axes[na++] = a;
+    const size_t bytes = (size_t)Z * Y * X * sizeof(float);
+    if (na == 0) {
+        if (d_in != d_out) FDN_HIP(hipMemcpyAsync(d_out, d_in, bytes, hipMemcpyDeviceToDevice, h->stream));
+        return 0;
+    }
+    // ping-pong so that the last pass lands in d_out and the input is never written
+    const float* src = d_in;
+    for (int i = 0; i < na; i++) {
+        float* dst;
+        if (i == na - 1) dst = d_out;
+        else {
+            DevBuf& b = (i & 1) ? h->vol_b : h->vol_a;
+            if (ensure(h, b, bytes)) return -1;
+            dst = (float*)b.p;
+        }
+        if (src == dst) return fail("in and out must not alias");
+        int a = axes[i];
+        if (filter_axis_dev(h, src, dst, Z, Y, X, a, kernels[a], K[a], pad_value, p)) return -1;
+        src = dst;
+    }
+    return 0;
+}
+
+// ---- exported C ABI ---------------------------------------------------------------
+extern "C" {
+
+#define FDN_API __attribute__((visibility("default")))
+
+FDN_API const char* fdn_last_error(void) { return g_err.c_str(); }
+FDN_API const char* fdn_version(void) { return "flowdn 0.1 gfx950"; }
+
+FDN_API int fdn_create(int device, fdn_handle* out)
+{
+    if (!out) return fail("out is NULL");
+    int ndev = 0;
+    FDN_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("device %d out of range (have %d)", device, ndev);
+    FDN_HIP(hipSetDevice(device));
+    fdn_ctx* h = new fdn_ctx();
+    h->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    h->stream = h->own_stream;
+    (void)hipEventCreate(&h->ev0);
+    (void)hipEventCreate(&h->ev1);
+    *out = h;
+    return 0;
+}
+
+FDN_API int fdn_destroy(fdn_handle h)
+{
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    DevBuf* bufs[] = {&h->R, &h->M0, &h->M1, &h->flow, &h->stack, &h->sweep_out, &h->vol_a, &h->vol_b, &h->partials, &h->pair};
+    for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return 0;
+}
+
+#define FDN_ENTER(h)                              \
+    if (!(h)) return fail("handle is NULL");      \
+    FDN_HIP(hipSetDevice((h)->device))
+
+FDN_API int fdn_set_stream(fdn_handle h, void* s)
+{
+    FDN_ENTER(h);
+    FDN_HIP(hipStreamSynchronize(h->stream));
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return 0;
+}
+FDN_API int fdn_synchronize(fdn_handle h)
+{
+    FDN_ENTER(h);
+    FDN_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+FDN_API int fdn_set_workspace_limit(fdn_handle h, size_t bytes)
+{
+    FDN_ENTER(h);
+    h->ws_limit = bytes;
+    return 0;
+}
+FDN_API int fdn_malloc(fdn_handle h, size_t bytes, void** dptr)
+{
+    FDN_ENTER(h);
+    if (!dptr) return fail("dptr is NULL");
+    FDN_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    return 0;
+}
+FDN_API int fdn_free(fdn_handle h, void* dptr)
+{
+    FDN_ENTER(h);
+    FDN_HIP(hipStreamSynchronize(h->stream));
+    if (dptr) FDN_HIP(hipFree(dptr));
+    return 0;
+}
+FDN_API int fdn_memcpy_h2d(fdn_handle h, void* dst, const void* src, size_t bytes)
+{
+    FDN_ENTER(h);
+    ScopedTimer t(h, FDN_TIMER_TRANSFER);
+    FDN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    FDN_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+FDN_API int fdn_memcpy_d2h(fdn_handle h, void* dst, const void* src, size_t bytes)
+{
+    FDN_ENTER(h);
+    ScopedTimer t(h, FDN_TIMER_TRANSFER);
+    FDN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    FDN_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+FDN_API int fdn_memset_f32(fdn_handle h, float* dst, float value, size_t count)
+{
+    FDN_ENTER(h);
+    launch_fill(dst, value, count, h->stream);
+    FDN_HIP(hipGetLastError());
+    return 0;
+}
+
+// a-1 (seq:30-41): scipy.ndimage.gaussian_filter1d's kernel, truncate = 4
+FDN_API int fdn_gaussian_kernel(double sigma, double* out, int cap)
+{
+    if (!(sigma > 0)) return fail("sigma must be > 0");
+    int r = (int)(4.0 * sigma + 0.5);
+    int K = 2 * r + 1;
+    if (!out || K > cap) return -K;
+    double sigma2 = sigma * sigma, s = 0;
+    for (int j = -r; j <= r; j++) { out[j + r] = exp(-0.5 / sigma2 * (double)(j * j)); s += out[j + r]; }
+    for (int i = 0; i < K; i++) out[i] /= s;
+    return K;
+}
+
+FDN_API int fdn_farneback(fdn_handle h, const float* prev, const float* next, float* flow_io, int H, int W,
+                          int levels, int winsize, int iters, int poly_n, double poly_sigma, int flags)
+{
+    FDN_ENTER(h);
+    if (!prev || !next || !flow_io) return fail("NULL image/flow pointer");
+    if (H <= 0 || W <= 0) return fail("bad image dims");
+    if (flags & ~FDN_USE_INITIAL_FLOW) return fail("unsupported flags 0x%x (only OPTFLOW_USE_INITIAL_FLOW)", flags);
+    fdn_sweep_params p{levels, winsize, iters, poly_n, poly_sigma, 0, 1, 1};
+    if (check_params(&p, 1)) return -1;
+    if (effective_levels(levels, H, W) > 0)
+        return fail("levels > 0 on %dx%d images needs the pyramid path, which this build does not have yet", W, H);
+    const size_t HW = (size_t)H * W;
+    hipStream_t st = h->stream;
+    // pair scratch: [prev, next] images | R x2 | flow | M0 | M1
+    size_t need = HW * 4 * (2 + 10 + 2 + 5 + 5);
+    if (ensure(h, h->pair, need)) return -1;
+    float* img = (float*)h->pair.p;
+    float* R = img + 2 * HW;
+    float* flow = R + 10 * HW;
+    float* M0 = flow + 2 * HW;
+    float* M1 = M0 + 5 * HW;
+    {
+        ScopedTimer t(h, FDN_TIMER_TRANSFER);
+        FDN_HIP(hipMemcpyAsync(img, prev, HW * 4, hipMemcpyHostToDevice, st));
+        FDN_HIP(hipMemcpyAsync(img + HW, next, HW * 4, hipMemcpyHostToDevice, st));
+        if (flags & FDN_USE_INITIAL_FLOW) FDN_HIP(hipMemcpyAsync(flow, flow_io, HW * 8, hipMemcpyHostToDevice, st));
+        else launch_fill(flow, 0.f, HW * 2, st);
+    }
+    PolyConsts pc;
+    prepare_poly_consts(poly_n, poly_sigma, &pc);
+    {
+        ScopedTimer t(h, FDN_TIMER_POLYEXP);
+        launch_blur3_polyexp(img, R, 2, H, W, pc, st);
+    }
+    {
+        ScopedTimer t(h, FDN_TIMER_FLOW);
+        run_iterations(h, R, flow, M0, M1, PairBatch{1, 0, 1}, H, W, winsize, iters);
+    }
+    FDN_HIP(hipGetLastError());
+    {
+        ScopedTimer t(h, FDN_TIMER_TRANSFER);
+        FDN_HIP(hipMemcpyAsync(flow_io, flow, HW * 8, hipMemcpyDeviceToHost, st));
+        FDN_HIP(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+FDN_API int fdn_warp(fdn_handle h, const float* reference, const float* flow, float* dst, int H, int W)
+{
+    FDN_ENTER(h);
+    if (!reference || !flow || !dst) return fail("NULL pointer");
+    if (H <= 0 || W <= 0) return fail("bad image dims");
+    const size_t HW = (size_t)H * W;
+    hipStream_t st = h->stream;
+    if (ensure(h, h->pair, HW * 4 * 4)) return -1;
+    float* d_src = (float*)h->pair.p;
+    float* d_flow = d_src + HW;
+    float* d_dst = d_flow + 2 * HW;
+    FDN_HIP(hipMemcpyAsync(d_src, reference, HW * 4, hipMemcpyHostToDevice, st));
+    FDN_HIP(hipMemcpyAsync(d_flow, flow, HW * 8, hipMemcpyHostToDevice, st));
+    launch_warp(d_src, d_flow, d_dst, H, W, st);
+    FDN_HIP(hipGetLastError());
+    FDN_HIP(hipMemcpyAsync(dst, d_dst, HW * 4, hipMemcpyDeviceToHost, st));
+    FDN_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+FDN_API int fdn_filter_axis_dev(fdn_handle h, const float* d_in, float* d_out, int Z, int Y, int X, int axis,
+                                const double* kernel, int K, float pad_value, const fdn_sweep_params* p)
+{
+    FDN_ENTER(h);
+    if (!d_in || !d_out || !kernel) return fail("NULL pointer");
+    return filter_axis_dev(h, d_in, d_out, Z, Y, X, axis, kernel, K, pad_value, p);
+}
+
+FDN_API int fdn_filter_3d_dev(fdn_handle h, const float* d_in, float* d_out, int Z, int Y, int X,
+                              const double* const kernels[3], const int K[3], float pad_value, const fdn_sweep_params* p)
+{
+    FDN_ENTER(h);
+    if (!d_in || !d_out) return fail("NULL pointer");
+    return filter_3d_dev(h, d_in, d_out, Z, Y, X, kernels, K, pad_value, p);
+}
+
+static int host_roundtrip(fdn_ctx* h, const float* in, float* out, size_t count, float** d_in, float** d_out)
+{
+    if (ensure(h, h->vol_b, count * sizeof(float) * 2)) return -1;
+    *d_in = (float*)h->vol_b.p;
+    *d_out = *d_in + count;
+    ScopedTimer t(h, FDN_TIMER_TRANSFER);
+    FDN_HIP(hipMemcpyAsync(*d_in, in, count * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    (void)out;
+    return 0;
+}
+
+FDN_API int fdn_filter_axis(fdn_handle h, const float* in, float* out, int Z, int Y, int X, int axis,
+                            const double* kernel, int K, float pad_value, const fdn_sweep_params* p)
+{
+    FDN_ENTER(h);
+    if (!in || !out || !kernel) return fail("NULL pointer");
+    if (Z <= 0 || Y <= 0 || X <= 0) return fail("bad volume dims");
+    size_t count = (size_t)Z * Y * X;
+    // vol_b holds [in | out]; filter_3d_dev's ping-pong never uses vol_b for a single axis
+    float *d_in, *d_out;
+    if (host_roundtrip(h, in, out, count, &d_in, &d_out)) return -1;
+    if (filter_axis_dev(h, d_in, d_out, Z, Y, X, axis, kernel, K, pad_value, p)) return -1;
+    ScopedTimer t(h, FDN_TIMER_TRANSFER);
+    FDN_HIP(hipMemcpyAsync(out, d_out, count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    FDN_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+FDN_API int fdn_filter_3d(fdn_handle h, const float* in, float* out, int Z, int Y, int X,
+                          const double* const kernels[3], const int K[3], float pad_value, const fdn_sweep_params* p)
+{
+    FDN_ENTER(h);
+    if (!in || !out) return fail("NULL pointer");
+    if (Z <= 0 || Y <= 0 || X <= 0) return fail("bad volume dims");
+    size_t count = (size_t)Z * Y * X;
+    void *d_in = nullptr, *d_out = nullptr;
+    FDN_HIP(hipMalloc(&d_in, count * sizeof(float)));
+    hipError_t e = hipMalloc(&d_out, count * sizeof(float));
+    if (e != hipSuccess) { (void)hipFree(d_in); return fail("hipMalloc failed: %s", hipGetErrorString(e)); }
+    int rc = 0;
+    {
+        ScopedTimer t(h, FDN_TIMER_TRANSFER);
+        if (hipMemcpyAsync(d_in, in, count * sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = fail("H2D failed");
+    }
+    if (!rc) rc = filter_3d_dev(h, (const float*)d_in, (float*)d_out, Z, Y, X, kernels, K, pad_value, p);
+    if (!rc) {
+        ScopedTimer t(h, FDN_TIMER_TRANSFER);
+        if (hipMemcpyAsync(out, d_out, count * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = fail("D2H failed");
+    }
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+FDN_API int fdn_sum_dev(fdn_handle h, const float* d_in, size_t count, double* sum_out)
+{
+    FDN_ENTER(h);
+    if (!d_in || !sum_out) return fail("NULL pointer");
+    const int MAXB = 4096;
+    if (ensure(h, h->partials, MAXB * sizeof(double))) return -1;
+    int nb = launch_sum_partials(d_in, count, (double*)h->partials.p, MAXB, h->stream);
+    FDN_HIP(hipGetLastError());
+    std::vector<double> host(nb);
+    FDN_HIP(hipMemcpyAsync(host.data(), h->partials.p, nb * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    FDN_HIP(hipStreamSynchronize(h->stream));
+    double s = 0;
+    for (int i = 0; i < nb; i++) s += host[i];
+    *sum_out = s;
+    return 0;
+}
+
+FDN_API int fdn_mean_dev(fdn_handle h, const float* d_in, size_t count, float* mean_out)
+{
+    if (!mean_out) return fail("NULL pointer");
+    if (!count) return fail("empty volume");
+    double s = 0;
+    if (fdn_sum_dev(h, d_in, count, &s)) return -1;
+    *mean_out = (float)(s / (double)count);
+    return 0;
+}
+
+FDN_API int fdn_sweep_stack_dev(fdn_handle h, const float* d_stack, float* d_out, int S, int H, int W,
+                                const double* kernel, int K, const fdn_sweep_params* p)
+{
+    FDN_ENTER(h);
+    if (!d_stack || !d_out || !kernel) return fail("NULL pointer");
+    return sweep_stack(h, d_stack, d_out, S, H, W, kernel, K, p);
+}
+
+FDN_API int fdn_permute_dev(fdn_handle h, const float* d_in, float* d_out, int A, int B, int C,
+                            int64_t sa, int64_t sb, int64_t sc)
+{
+    FDN_ENTER(h);
+    if (!d_in || !d_out) return fail("NULL pointer");
+    if (A <= 0 || B <= 0 || C <= 0) return fail("bad dims");
+    if (sa != 1 && sb != 1 && sc != 1) return fail("one input stride must be 1");
+    ScopedTimer t(h, FDN_TIMER_PERMUTE);
+    launch_permute(d_in, d_out, A, B, C, sa, sb, sc, h->stream);
+    FDN_HIP(hipGetLastError());
+    return 0;
+}
+
+FDN_API int fdn_enable_timers(fdn_handle h, int on)
+{
+    FDN_ENTER(h);
+    h->timers = on != 0;
+    return 0;
+}
+FDN_API int fdn_get_timers(fdn_handle h, double* ms_out, int reset)
+{
+    FDN_ENTER(h);
+    if (ms_out) for (int i = 0; i < FDN_TIMER_COUNT; i++) ms_out[i] = h->tms[i];
+    if (reset) for (int i = 0; i < FDN_TIMER_COUNT; i++) h->tms[i] = 0;
+    return 0;
+}
+
+} // extern "C"

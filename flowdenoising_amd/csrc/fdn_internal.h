@@ -1,0 +1,76 @@
+// fdn_internal.h -- shared declarations between the C-ABI layer (fdn_api.hip) and the
+// gfx950 kernels (fdn_kernels.hip).  Not installed; the public surface is include/flowdn.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace fdn {
+
+// Polynomial-expansion constants (OpenCV FarnebackPrepareGaussian), passed by value.
+struct PolyConsts {
+    int n;                       // half-width: taps -n..n
+    float g[16], xg[16], xxg[16]; // index k = 0..n (g is even, xg odd, xxg even in k)
+    double ig11, ig03, ig33, ig55;
+};
+
+void prepare_poly_consts(int n, double sigma, PolyConsts* pc);
+
+// Runtime-tap Gaussian blur kernel (cv::getGaussianKernel, f32), max 63 taps.
+struct BlurTaps {
+    int n;
+    float k[64];
+};
+void prepare_blur_taps(int n, double sigma, BlurTaps* bt);
+
+// ---- launchers: all asynchronous on `st`, all pointers are device pointers ----------
+
+// R[s] = polyexp(blur3x3(img[s])) for s in [0, nslices): img slices are H*W apart,
+// R slices are 5*H*W apart (planar: plane c of slice s at R + (s*5 + c)*H*W).
+void launch_blur3_polyexp(const float* img, float* R, int nslices, int H, int W,
+                          const PolyConsts& pc, hipStream_t st);
+// same without the fused 3x3 blur (pyramid levels: the input is already blurred+resized)
+void launch_polyexp(const float* img, float* R, int nslices, int H, int W,
+                    const PolyConsts& pc, hipStream_t st);
+
+// Batched pair descriptors: for pair b in [0, npairs): target slice index t0 + b,
+// neighbour slice index t0 + b + d, both indices into the R / image stack.
+struct PairBatch {
+    int npairs;
+    int t0;      // stack index of the first target
+    int d;       // neighbour offset (signed)
+};
+
+// M[b] = UpdateMatrices(R[t], R[n], flow[b])    (M planar 5 x H x W per pair)
+void launch_update_matrices(const float* Rstack, const float* flow, float* M, PairBatch pb,
+                            int H, int W, hipStream_t st);
+// flow[b] = solve(box_w(Min[b])); if Mout: Mout[b] = UpdateMatrices(R[t], R[n], flow[b])
+void launch_update_flow(const float* Rstack, const float* Min, float* Mout, float* flow,
+                        PairBatch pb, int H, int W, int winsize, hipStream_t st);
+// acc[b] = f32( f64(acc[b]) + f64(remap(stack[n], flow[b])) * weight )
+void launch_warp_accumulate(const float* stack, const float* flow, float* acc, PairBatch pb,
+                            int H, int W, double weight, hipStream_t st);
+// acc[b] = f32( f64(acc[b]) + f64(stack[t0 + b + d]) * weight )   (centre tap, no-OF taps)
+void launch_axpy_slices(const float* stack, float* acc, PairBatch pb, int H, int W,
+                        double weight, hipStream_t st);
+// dst(y,x) = remap(src, flow)  single image (fdn_warp)
+void launch_warp(const float* src, const float* flow, float* dst, int H, int W, hipStream_t st);
+
+void launch_fill(float* dst, float value, size_t count, hipStream_t st);
+void launch_permute(const float* in, float* out, int A, int B, int C, int64_t sa, int64_t sb,
+                    int64_t sc, hipStream_t st);
+// partial sums (f64) into `partials` (nblocks entries); returns nblocks used
+int launch_sum_partials(const float* in, size_t count, double* partials, int max_blocks,
+                        hipStream_t st);
+
+// pyramid pieces (levels > 0)
+void launch_gaussian_blur(const float* in, float* tmp, float* out, int nimg, int H, int W,
+                          const BlurTaps& bt, hipStream_t st);
+// cv::resize as FarnebackOpticalFlowImpl::calc uses it, nimg images of cn interleaved
+// channels: interp 1 = INTER_LINEAR (an exact 2x2 shrink is promoted to area, as cv::resize
+// does), 3 = INTER_AREA (integer ratios on this path).  If apply_ps, each result is then
+// multiplied by ps in f64 (the "flow *= scale" of calc).
+void resize_images(const float* in, int sh, int sw, float* out, int dh, int dw, int cn, int nimg,
+                   int interp, bool apply_ps, double ps, hipStream_t st);
+
+} // namespace fdn

@@ -1,0 +1,576 @@
+// fdn_kernels.hip -- gfx950 (MI355X, wave64) kernels of the FlowDenoising hot path.
+//
+// General ("staged") path: one kernel per Farneback stage, batched over all target
+// slices of a sweep step.  Works for any winsize / image size and is what the pyramid
+// levels and the pair-level entry points use.  The fused fast path for the default
+// configuration lives in fdn_fused.hip.
+//
+// Arithmetic follows OpenCV's operand types expression by expression (see
+// oracle/fdn_oracle.c for the restatement and the reference call sites,
+// src/flowdenoising_sequential.py:56,62); the file is compiled with -ffp-contract=off so
+// that the compiler does not fuse multiplies and adds the CPU code keeps separate.
+// Layouts: images [H][W] f32; polynomial expansion R and matrices M are PLANAR,
+// 5 planes of [H][W] (coalesced along x for both the aligned reads and the bilinear
+// gathers); flow is interleaved (x,y) float2 as in cv2.
+#include "fdn_internal.h"
+
+namespace fdn {
+
+static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static __device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------
+// Polynomial expansion (FarnebackPolyExp), optionally fused with the level-0 3x3
+// binomial blur (GaussianBlur(ksize 3, sigma 0) -> taps .25 .5 .25, reflect-101).
+// Block = 256 threads, output tile 64 x 16; LDS: blurred tile with halo n, then the
+// three vertical-pass rows.
+// ---------------------------------------------------------------------------------
+constexpr int PE_TW = 64, PE_TH = 16, PE_MAXN = 7;
+
+static __device__ __forceinline__ float blur3_at(const float* __restrict__ img, int H, int W, int cy, int cx)
+{
+    int xl = reflect101(cx - 1, W), xr = reflect101(cx + 1, W);
+    float t[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        int yy = reflect101(cy + r - 1, H);
+        const float* S = img + (size_t)yy * W;
+        t[r] = S[cx] * 0.5f + (S[xl] + S[xr]) * 0.25f;
+    }
+    return 0.5f * t[1] + 0.25f * (t[2] + t[0]);
+}
+
+template <bool FUSE_BLUR3>
+__global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img_base, float* __restrict__ R_base,
+                                                 int H, int W, PolyConsts pc)
+{
+    __shared__ float sB[(PE_TH + 2 * PE_MAXN) * (PE_TW + 2 * PE_MAXN)];
+    __shared__ float sRow[3][PE_TH][PE_TW + 2 * PE_MAXN];
+    const int n = pc.n;
+    const int LW = PE_TW + 2 * n, LH = PE_TH + 2 * n;
+    const size_t HW = (size_t)H * W;
+    const float* img = img_base + (size_t)blockIdx.z * HW;
+    float* R = R_base + (size_t)blockIdx.z * 5 * HW;
+    const int x0 = blockIdx.x * PE_TW, y0 = blockIdx.y * PE_TH;
+
+    for (int idx = threadIdx.x; idx < LW * LH; idx += 256) {
+        int ty = idx / LW, tx = idx - ty * LW;
+        int cy = clampi(y0 - n + ty, 0, H - 1), cx = clampi(x0 - n + tx, 0, W - 1);
+        sB[ty * LW + tx] = FUSE_BLUR3 ? blur3_at(img, H, W, cy, cx) : img[(size_t)cy * W + cx];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < LW * PE_TH; idx += 256) {
+        int ry = idx / LW, tx = idx - ry * LW;
+        const float* c = sB + (ry + n) * LW + tx;
+        float r0 = c[0] * pc.g[0], r1 = 0.f, r2 = 0.f;
+        for (int k = 1; k <= n; k++) {
+            float s0 = c[-k * LW], s1 = c[k * LW];
+            float p = s0 + s1;
+            r0 = r0 + pc.g[k] * p;
+            r1 = r1 + pc.xg[k] * (s1 - s0);
+            r2 = r2 + pc.xxg[k] * p;
+        }
+        sRow[0][ry][tx] = r0; sRow[1][ry][tx] = r1; sRow[2][ry][tx] = r2;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < PE_TW * PE_TH; idx += 256) {
+        int ry = idx / PE_TW, ox = idx - ry * PE_TW;
+        int x = x0 + ox, y = y0 + ry;
+        if (x >= W || y >= H) continue;
+        const float* a0 = &sRow[0][ry][ox + n];
+        const float* a1 = &sRow[1][ry][ox + n];
+        const float* a2 = &sRow[2][ry][ox + n];
+        float g0 = pc.g[0];
+        double b1 = (double)(a0[0] * g0), b2 = 0, b3 = (double)(a1[0] * g0), b4 = 0, b5 = (double)(a2[0] * g0), b6 = 0;
+        for (int k = 1; k <= n; k++) {
+            float gk = pc.g[k], xgk = pc.xg[k], xxgk = pc.xxg[k];
+            double tg = (double)(a0[k] + a0[-k]);
+            b1 += tg * (double)gk;
+            b4 += tg * (double)xxgk;
+            b2 += (double)((a0[k] - a0[-k]) * xgk);
+            b3 += (double)((a1[k] + a1[-k]) * gk);
+            b6 += (double)((a1[k] - a1[-k]) * xgk);
+            b5 += (double)((a2[k] + a2[-k]) * gk);
+        }
+        size_t o = (size_t)y * W + x;
+        R[o] = (float)(b3 * pc.ig11);
+        R[HW + o] = (float)(b2 * pc.ig11);
+        R[2 * HW + o] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+        R[3 * HW + o] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+        R[4 * HW + o] = (float)(b6 * pc.ig55);
+    }
+}
+
+void launch_blur3_polyexp(const float* img, float* R, int nslices, int H, int W, const PolyConsts& pc, hipStream_t st)
+{
+    if (nslices <= 0) return;
+    dim3 grid((W + PE_TW - 1) / PE_TW, (H + PE_TH - 1) / PE_TH, nslices);
+    hipLaunchKernelGGL(k_polyexp<true>, grid, dim3(256), 0, st, img, R, H, W, pc);
+}
+void launch_polyexp(const float* img, float* R, int nslices, int H, int W, const PolyConsts& pc, hipStream_t st)
+{
+    if (nslices <= 0) return;
+    dim3 grid((W + PE_TW - 1) / PE_TW, (H + PE_TH - 1) / PE_TH, nslices);
+    hipLaunchKernelGGL(k_polyexp<false>, grid, dim3(256), 0, st, img, R, H, W, pc);
+}
+
+// ---------------------------------------------------------------------------------
+// FarnebackUpdateMatrices for one pixel.  r0[5]: R0 at (x,y); R1: planar neighbour
+// expansion (gathered bilinearly at (x+dx, y+dy), exact f32 weights, no quantisation).
+// ---------------------------------------------------------------------------------
+static __device__ __forceinline__ void compute_M(const float r0[5], const float* __restrict__ R1, size_t HW,
+                                                 int H, int W, int x, int y, float dx, float dy, float m[5])
+{
+    float fx = (float)x + dx, fy = (float)y + dy;
+    float flx = floorf(fx), fly = floorf(fy);
+    int x1 = (int)flx, y1 = (int)fly;
+    fx -= flx; fy -= fly;
+    float r2, r3, r4, r5, r6;
+    if ((unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1)) {
+        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        const float* p = R1 + (size_t)y1 * W + x1;
+        r2 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += HW;
+        r3 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += HW;
+        r4 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += HW;
+        r5 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += HW;
+        r6 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1];
+        r4 = (r0[2] + r4) * 0.5f;
+        r5 = (r0[3] + r5) * 0.5f;
+        r6 = (r0[4] + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = r0[2];
+        r5 = r0[3];
+        r6 = r0[4] * 0.5f;
+    }
+    r2 = (r0[0] - r2) * 0.5f;
+    r3 = (r0[1] - r3) * 0.5f;
+    r2 = r2 + (r4 * dy + r6 * dx);
+    r3 = r3 + (r6 * dy + r5 * dx);
+    const int BORDER = 5;
+    if ((unsigned)(x - BORDER) >= (unsigned)(W - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(H - BORDER * 2)) {
+        // border[] = {0.14, 0.14, 0.4472, 0.4472, 0.4472}
+        float bx0 = x < BORDER ? (x < 2 ? 0.14f : 0.4472f) : 1.f;
+        float bx1 = x >= W - BORDER ? (W - x - 1 < 2 ? 0.14f : 0.4472f) : 1.f;
+        float by0 = y < BORDER ? (y < 2 ? 0.14f : 0.4472f) : 1.f;
+        float by1 = y >= H - BORDER ? (H - y - 1 < 2 ? 0.14f : 0.4472f) : 1.f;
+        float scale = bx0 * bx1 * by0 * by1;
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
+    m[0] = r4 * r4 + r6 * r6;
+    m[1] = (r4 + r5) * r6;
+    m[2] = r5 * r5 + r6 * r6;
+    m[3] = r4 * r2 + r6 * r3;
+    m[4] = r6 * r2 + r5 * r3;
+}
+
+__global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict__ Rstack, const float* __restrict__ flow_base,
+                                                         float* __restrict__ M_base, PairBatch pb, int H, int W)
+{
+    const size_t HW = (size_t)H * W;
+    const int b = blockIdx.z;
+    const float* R0 = Rstack + (size_t)(pb.t0 + b) * 5 * HW;
+    const float* R1 = Rstack + (size_t)(pb.t0 + b + pb.d) * 5 * HW;
+    const float2* flow = (const float2*)flow_base + (size_t)b * HW;
+    float* M = M_base + (size_t)b * 5 * HW;
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    size_t o = (size_t)y * W + x;
+    float r0[5], m[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) r0[c] = R0[c * HW + o];
+    float2 f = flow[o];
+    compute_M(r0, R1, HW, H, W, x, y, f.x, f.y, m);
+#pragma unroll
+    for (int c = 0; c < 5; c++) M[c * HW + o] = m[c];
+}
+
+void launch_update_matrices(const float* Rstack, const float* flow, float* M, PairBatch pb, int H, int W, hipStream_t st)
+{
+    if (pb.npairs <= 0) return;
+    dim3 grid((W + 63) / 64, (H + 3) / 4, pb.npairs);
+    hipLaunchKernelGGL(k_update_matrices, grid, dim3(256), 0, st, Rstack, flow, M, pb, H, W);
+}
+
+// ---------------------------------------------------------------------------------
+// FarnebackUpdateFlow_Blur: (2m+1)^2 box sum of M (replicate borders, f64 like OpenCV's
+// vsum / g11..h2, as DIRECT window sums rather than running sums), 2x2 solve in f64,
+// then optionally the matrix refresh for the next iteration.
+// Block 256 threads, tile 32 x 16, dynamic LDS: M tile with halo m (f32) + vertical
+// sums (f64).
+// ---------------------------------------------------------------------------------
+constexpr int UF_TW = 32, UF_TH = 16;
+
+static __device__ __forceinline__ float2 solve_flow(const double a[5], double scale)
+{
+    double g11 = a[0] * scale, g12 = a[1] * scale, g22 = a[2] * scale, h1 = a[3] * scale, h2 = a[4] * scale;
+    double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+    float2 f;
+    f.x = (float)((g11 * h2 - g12 * h1) * idet);
+    f.y = (float)((g22 * h1 - g12 * h2) * idet);
+    return f;
+}
+
+__global__ __launch_bounds__(256) void k_update_flow(const float* __restrict__ Rstack, const float* __restrict__ Min_base,
+                                                     float* __restrict__ Mout_base, float* __restrict__ flow_base,
+                                                     PairBatch pb, int H, int W, int m, double scale)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int LW = UF_TW + 2 * m, LH = UF_TH + 2 * m;
+    double* sV = (double*)smem;                               // [5][UF_TH][LW]
+    float* sM = (float*)(smem + (size_t)5 * UF_TH * LW * 8);  // [5][LH][LW]
+    const size_t HW = (size_t)H * W;
+    const int b = blockIdx.z;
+    const float* Min = Min_base + (size_t)b * 5 * HW;
+    const int x0 = blockIdx.x * UF_TW, y0 = blockIdx.y * UF_TH;
+
+    for (int idx = threadIdx.x; idx < LW * LH; idx += 256) {
+        int ty = idx / LW, tx = idx - ty * LW;
+        int cy = clampi(y0 - m + ty, 0, H - 1), cx = clampi(x0 - m + tx, 0, W - 1);
+        size_t o = (size_t)cy * W + cx;
+#pragma unroll
+        for (int c = 0; c < 5; c++) sM[(c * LH + ty) * LW + tx] = Min[c * HW + o];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < LW * UF_TH; idx += 256) {
+        int ry = idx / LW, tx = idx - ry * LW;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const float* p = sM + (c * LH + ry) * LW + tx;
+            double s = 0;
+            for (int j = 0; j <= 2 * m; j++) s += (double)p[j * LW];
+            sV[(c * UF_TH + ry) * LW + tx] = s;
+        }
+    }
+    __syncthreads();
+    const float* R0 = Rstack + (size_t)(pb.t0 + b) * 5 * HW;
+    const float* R1 = Rstack + (size_t)(pb.t0 + b + pb.d) * 5 * HW;
+    float2* flow = (float2*)flow_base + (size_t)b * HW;
+    float* Mout = Mout_base ? Mout_base + (size_t)b * 5 * HW : nullptr;
+    for (int idx = threadIdx.x; idx < UF_TW * UF_TH; idx += 256) {
+        int ry = idx / UF_TW, ox = idx - ry * UF_TW;
+        int x = x0 + ox, y = y0 + ry;
+        if (x >= W || y >= H) continue;
+        double a[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const double* p = sV + (c * UF_TH + ry) * LW + ox;
+            double s = 0;
+            for (int i = 0; i <= 2 * m; i++) s += p[i];
+            a[c] = s;
+        }
+        float2 f = solve_flow(a, scale);
+        size_t o = (size_t)y * W + x;
+        flow[o] = f;
+        if (Mout) {
+            float r0[5], mm[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) r0[c] = R0[c * HW + o];
+            compute_M(r0, R1, HW, H, W, x, y, f.x, f.y, mm);
+#pragma unroll
+            for (int c = 0; c < 5; c++) Mout[c * HW + o] = mm[c];
+        }
+    }
+}
+
+void launch_update_flow(const float* Rstack, const float* Min, float* Mout, float* flow, PairBatch pb,
+                        int H, int W, int winsize, hipStream_t st)
+{
+    if (pb.npairs <= 0) return;
+    int m = winsize / 2;
+    double scale = 1. / ((double)winsize * winsize);
+    int LW = UF_TW + 2 * m, LH = UF_TH + 2 * m;
+    size_t lds = (size_t)5 * UF_TH * LW * 8 + (size_t)5 * LH * LW * 4;
+    dim3 grid((W + UF_TW - 1) / UF_TW, (H + UF_TH - 1) / UF_TH, pb.npairs);
+    hipLaunchKernelGGL(k_update_flow, grid, dim3(256), lds, st, Rstack, Min, Mout, flow, pb, H, W, m, scale);
+}
+
+// ---------------------------------------------------------------------------------
+// warp_slice: map = f32(f64(flow) + grid) (numpy's f32 + int64 promotion), then
+// cv2.remap INTER_LINEAR / BORDER_REPLICATE: coordinates rounded half-even to 1/32 px,
+// weights (1-a/32)(1-b/32)..., four clamped taps, f32 left-to-right sum.
+// ---------------------------------------------------------------------------------
+static __device__ __forceinline__ float remap_sample(const float* __restrict__ src, int H, int W, int x, int y, float2 f)
+{
+    float mx = (float)((double)f.x + (double)x);
+    float my = (float)((double)f.y + (double)y);
+    // cvRound(v * INTER_TAB_SIZE); bounded so the int conversion is defined for wild flows
+    float qx = fminf(fmaxf(rintf(mx * 32.f), -2147483520.f), 2147483520.f);
+    float qy = fminf(fmaxf(rintf(my * 32.f), -2147483520.f), 2147483520.f);
+    int sx = (int)qx, sy = (int)qy;
+    int ax = sx & 31, ay = sy & 31;
+    int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);
+    float tx1 = (float)ax * (1.f / 32), tx0 = 1.f - tx1;
+    float ty1 = (float)ay * (1.f / 32), ty0 = 1.f - ty1;
+    float w0 = ty0 * tx0, w1 = ty0 * tx1, w2 = ty1 * tx0, w3 = ty1 * tx1;
+    int xa = clampi(ix, 0, W - 1), xb = clampi(ix + 1, 0, W - 1);
+    int ya = clampi(iy, 0, H - 1), yb = clampi(iy + 1, 0, H - 1);
+    const float* ra = src + (size_t)ya * W;
+    const float* rb = src + (size_t)yb * W;
+    float v0 = ra[xa], v1 = ra[xb], v2 = rb[xa], v3 = rb[xb];
+    return v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
+}
+
+__global__ __launch_bounds__(256) void k_warp_accumulate(const float* __restrict__ stack, const float* __restrict__ flow_base,
+                                                         float* __restrict__ acc_base, PairBatch pb, int H, int W, double weight)
+{
+    const size_t HW = (size_t)H * W;
+    const int b = blockIdx.z;
+    const float* src = stack + (size_t)(pb.t0 + b + pb.d) * HW;
+    const float2* flow = (const float2*)flow_base + (size_t)b * HW;
+    float* acc = acc_base + (size_t)b * HW;
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    size_t o = (size_t)y * W + x;
+    float v = remap_sample(src, H, W, x, y, flow[o]);
+    acc[o] = (float)((double)acc[o] + (double)v * weight);
+}
+
+void launch_warp_accumulate(const float* stack, const float* flow, float* acc, PairBatch pb, int H, int W,
+                            double weight, hipStream_t st)
+{
+    if (pb.npairs <= 0) return;
+    dim3 grid((W + 63) / 64, (H + 3) / 4, pb.npairs);
+    hipLaunchKernelGGL(k_warp_accumulate, grid, dim3(256), 0, st, stack, flow, acc, pb, H, W, weight);
+}
+
+__global__ __launch_bounds__(256) void k_warp(const float* __restrict__ src, const float* __restrict__ flow_base,
+                                              float* __restrict__ dst, int H, int W)
+{
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    size_t o = (size_t)y * W + x;
+    dst[o] = remap_sample(src, H, W, x, y, ((const float2*)flow_base)[o]);
+}
+void launch_warp(const float* src, const float* flow, float* dst, int H, int W, hipStream_t st)
+{
+    dim3 grid((W + 63) / 64, (H + 3) / 4, 1);
+    hipLaunchKernelGGL(k_warp, grid, dim3(256), 0, st, src, flow, dst, H, W);
+}
+
+__global__ __launch_bounds__(256) void k_axpy_slices(const float* __restrict__ stack, float* __restrict__ acc_base,
+                                                     PairBatch pb, size_t HW, double weight)
+{
+    const int b = blockIdx.y;
+    const float* src = stack + (size_t)(pb.t0 + b + pb.d) * HW;
+    float* acc = acc_base + (size_t)b * HW;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < HW; o += (size_t)gridDim.x * 256)
+        acc[o] = (float)((double)acc[o] + (double)src[o] * weight);
+}
+void launch_axpy_slices(const float* stack, float* acc, PairBatch pb, int H, int W, double weight, hipStream_t st)
+{
+    if (pb.npairs <= 0) return;
+    size_t HW = (size_t)H * W;
+    int gx = (int)((HW + 255) / 256); if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_axpy_slices, dim3(gx, pb.npairs), dim3(256), 0, st, stack, acc, pb, HW, weight);
+}
+
+__global__ __launch_bounds__(256) void k_fill(float* __restrict__ dst, float value, size_t count)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) dst[i] = value;
+}
+void launch_fill(float* dst, float value, size_t count, hipStream_t st)
+{
+    if (!count) return;
+    size_t g = (count + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)g), dim3(256), 0, st, dst, value, count);
+}
+
+// ---------------------------------------------------------------------------------
+// permute: out[a][b][c] = in[a*sa + b*sb + c*sc], out contiguous (A,B,C).
+// sc == 1: row copies.  Otherwise a 32x32 LDS-tiled transpose over the out dims
+// (u, C) where u is the out dim whose in-stride is 1, so both sides stay coalesced.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_permute_rows(const float* __restrict__ in, float* __restrict__ out,
+                                                      int A, int B, int C, int64_t sa, int64_t sb)
+{
+    int64_t ab = blockIdx.x;
+    int a = (int)(ab / B), b = (int)(ab - (int64_t)a * B);
+    const float* src = in + a * sa + b * sb;
+    float* dst = out + ab * C;
+    for (int c = threadIdx.x; c < C; c += 256) dst[c] = src[c];
+}
+// MODE 0: in-stride-1 dim is B (tile over b,c; grid.z = a).  MODE 1: it is A (tile over a,c; grid.z = b).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_permute_tiled(const float* __restrict__ in, float* __restrict__ out,
+                                                       int A, int B, int C, int64_t sa, int64_t sb, int64_t sc)
+{
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    const int U = MODE == 0 ? B : A;
+    const int u0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int other = blockIdx.z;
+    const int64_t base_in = MODE == 0 ? (int64_t)other * sa : (int64_t)other * sb;
+    const int64_t su = MODE == 0 ? sb : sa; // == 1
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        int u = u0 + tx, c = c0 + ty + r;
+        if (u < U && c < C) tile[ty + r][tx] = in[base_in + (int64_t)u * su + (int64_t)c * sc];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        int u = u0 + ty + r, c = c0 + tx;
+        if (u < U && c < C) {
+            int a = MODE == 0 ? other : u, b = MODE == 0 ? u : other;
+            out[((int64_t)a * B + b) * C + c] = tile[tx][ty + r];
+        }
+    }
+}
+void launch_permute(const float* in, float* out, int A, int B, int C, int64_t sa, int64_t sb, int64_t sc, hipStream_t st)
+{
+    if (A <= 0 || B <= 0 || C <= 0) return;
+    if (sc == 1) {
+        hipLaunchKernelGGL(k_permute_rows, dim3((unsigned)((int64_t)A * B)), dim3(256), 0, st, in, out, A, B, C, sa, sb);
+    } else if (sb == 1) {
+        hipLaunchKernelGGL(k_permute_tiled<0>, dim3((B + 31) / 32, (C + 31) / 32, A), dim3(256), 0, st, in, out, A, B, C, sa, sb, sc);
+    } else { // sa == 1 (validated by the caller)
+        hipLaunchKernelGGL(k_permute_tiled<1>, dim3((A + 31) / 32, (C + 31) / 32, B), dim3(256), 0, st, in, out, A, B, C, sa, sb, sc);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// sum of a volume in f64 (for vol.mean(), seq:420)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ in, size_t count, double* __restrict__ partials)
+{
+    __shared__ double sh[4];
+    double s = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) s += (double)in[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+int launch_sum_partials(const float* in, size_t count, double* partials, int max_blocks, hipStream_t st)
+{
+    size_t g = (count + 255) / 256;
+    if (g > (size_t)max_blocks) g = max_blocks;
+    if (g == 0) g = 1;
+    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)g), dim3(256), 0, st, in, count, partials);
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------------
+// Pyramid pieces (levels > 0): cv::GaussianBlur with runtime taps, cv::resize
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blur_h(const float* __restrict__ in, float* __restrict__ out, int H, int W, BlurTaps bt)
+{
+    const size_t HW = (size_t)H * W;
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const float* S = in + (size_t)blockIdx.z * HW + (size_t)y * W;
+    const int n = bt.n, c = n / 2;
+    float s0;
+    if (n == 3) {
+        s0 = S[x] * bt.k[1] + (S[reflect101(x - 1, W)] + S[reflect101(x + 1, W)]) * bt.k[2];
+    } else if (n == 5) {
+        s0 = S[x] * bt.k[2] + (S[reflect101(x - 1, W)] + S[reflect101(x + 1, W)]) * bt.k[3]
+             + (S[reflect101(x - 2, W)] + S[reflect101(x + 2, W)]) * bt.k[4];
+    } else {
+        s0 = bt.k[0] * S[reflect101(x - c, W)];
+        for (int j = 1; j < n; j++) s0 = s0 + bt.k[j] * S[reflect101(x - c + j, W)];
+    }
+    out[(size_t)blockIdx.z * HW + (size_t)y * W + x] = s0;
+}
+__global__ __launch_bounds__(256) void k_blur_v(const float* __restrict__ in, float* __restrict__ out, int H, int W, BlurTaps bt)
+{
+    const size_t HW = (size_t)H * W;
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const float* T = in + (size_t)blockIdx.z * HW;
+    const int c = bt.n / 2;
+    float d = bt.k[c] * T[(size_t)y * W + x];
+    for (int j = 1; j <= c; j++) {
+        float sp = T[(size_t)reflect101(y + j, H) * W + x], sm = T[(size_t)reflect101(y - j, H) * W + x];
+        d = d + bt.k[c + j] * (sp + sm);
+    }
+    out[(size_t)blockIdx.z * HW + (size_t)y * W + x] = d;
+}
+void launch_gaussian_blur(const float* in, float* tmp, float* out, int nimg, int H, int W, const BlurTaps& bt, hipStream_t st)
+{
+    if (nimg <= 0) return;
+    dim3 grid((W + 63) / 64, (H + 3) / 4, nimg);
+    hipLaunchKernelGGL(k_blur_h, grid, dim3(256), 0, st, in, tmp, H, W, bt);
+    hipLaunchKernelGGL(k_blur_v, grid, dim3(256), 0, st, tmp, out, H, W, bt);
+}
+
+// INTER_LINEAR (HResizeLinear then VResizeLinear, f32 coefficients)
+template <int CN>
+__global__ __launch_bounds__(256) void k_resize_linear(const float* __restrict__ in, int sh, int sw, float* __restrict__ out,
+                                                       int dh, int dw, double scale_x, double scale_y, int apply_ps, double ps)
+{
+    int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    const float* src = in + (size_t)blockIdx.z * sh * sw * CN;
+    float* dst = out + (size_t)blockIdx.z * dh * dw * CN;
+    float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
+    float flx = floorf(fx); int sx = (int)flx; fx -= flx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
+    float fly = floorf(fy); int sy = (int)fly; fy -= fly;
+    if (sy < 0) { fy = 0; sy = 0; }
+    if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
+    int sx1 = sx + 1 < sw ? sx + 1 : sw - 1, sy1 = sy + 1 < sh ? sy + 1 : sh - 1;
+    float a1 = fx, a0 = 1.f - fx, b1 = fy, b0 = 1.f - fy;
+    const float* S0 = src + (size_t)sy * sw * CN;
+    const float* S1 = src + (size_t)sy1 * sw * CN;
+#pragma unroll
+    for (int ch = 0; ch < CN; ch++) {
+        float r0 = S0[sx * CN + ch] * a0 + S0[sx1 * CN + ch] * a1;
+        float r1 = S1[sx * CN + ch] * a0 + S1[sx1 * CN + ch] * a1;
+        float v = r0 * b0 + r1 * b1;
+        if (apply_ps) v = (float)((double)v * ps);
+        dst[((size_t)dy * dw + dx) * CN + ch] = v;
+    }
+}
+// INTER_AREA, integer ratios: f32 block sum in row-major order times 1/area
+template <int CN>
+__global__ __launch_bounds__(256) void k_resize_area_int(const float* __restrict__ in, int sh, int sw, float* __restrict__ out,
+                                                         int dh, int dw, int isx, int isy, int apply_ps, double ps)
+{
+    int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    const float* src = in + (size_t)blockIdx.z * sh * sw * CN;
+    float* dst = out + (size_t)blockIdx.z * dh * dw * CN;
+    float scale = 1.f / (float)(isx * isy);
+#pragma unroll
+    for (int ch = 0; ch < CN; ch++) {
+        float sum = 0;
+        for (int ky = 0; ky < isy; ky++)
+            for (int kx = 0; kx < isx; kx++)
+                sum = sum + src[((size_t)(dy * isy + ky) * sw + dx * isx + kx) * CN + ch];
+        float v = sum * scale;
+        if (apply_ps) v = (float)((double)v * ps);
+        dst[((size_t)dy * dw + dx) * CN + ch] = v;
+    }
+}
+// typed resize entry used by the pyramid driver
+void resize_images(const float* in, int sh, int sw, float* out, int dh, int dw, int cn, int nimg, int interp,
+                   bool apply_ps, double ps, hipStream_t st)
+{
+    if (nimg <= 0) return;
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4, nimg);
+    double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    int isx = (int)scale_x, isy = (int)scale_y;
+    bool integer = fabs(scale_x - isx) < 2.220446049250313e-16 && fabs(scale_y - isy) < 2.220446049250313e-16;
+    if (interp == 1 && integer && isx == 2 && isy == 2) interp = 3;
+    if (interp == 3 && scale_x >= 1 && scale_y >= 1 && integer) {
+        if (cn == 1) hipLaunchKernelGGL(k_resize_area_int<1>, grid, dim3(256), 0, st, in, sh, sw, out, dh, dw, isx, isy, (int)apply_ps, ps);
+        else hipLaunchKernelGGL(k_resize_area_int<2>, grid, dim3(256), 0, st, in, sh, sw, out, dh, dw, isx, isy, (int)apply_ps, ps);
+    } else {
+        if (cn == 1) hipLaunchKernelGGL(k_resize_linear<1>, grid, dim3(256), 0, st, in, sh, sw, out, dh, dw, scale_x, scale_y, (int)apply_ps, ps);
+        else hipLaunchKernelGGL(k_resize_linear<2>, grid, dim3(256), 0, st, in, sh, sw, out, dh, dw, scale_x, scale_y, (int)apply_ps, ps);
+    }
+}
+
+} // namespace fdn

@@ -1,0 +1,155 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+Same names, argument order and meaning as src/flowdenoising_sequential.py ("seq") and
+src/flowdenoising.py ("par") in the reference tree, so that code (and tests) written
+against the reference read the same here.  All arithmetic runs in libflowdn.so on the
+GPU; this module only marshals numpy arrays.  There is no CPU fallback.
+
+    get_gaussian_kernel(sigma)                      seq:30-41
+    get_flow(reference, target, l, w, prev_flow)    seq:59-67 / par:65-87
+    get_flow_without_prev_flow(...)                 par:89-114
+    warp_slice(reference, flow)                     seq:51-57
+    OF_filter_along_Z/Y/X(vol, kernel, l, w, mean)  seq:78-130 / 235-288 / 313-364
+    no_OF_filter_along_Z/Y/X(vol, kernel, mean)     seq:171-192 / 290-311 / 396-417
+    OF_filter(vol, kernel, l, w)                    seq:419-424
+    no_OF_filter(vol, kernel)                       seq:426-431
+    FlowDenoising(P, vol, l, w, ...).filter(kernels)   par:297-304, 285-290
+"""
+import numpy as np
+
+from . import _lib
+
+OF_LEVELS = 0          # seq:44  (par:48 uses 3)
+OF_WINDOW_SIZE = 5     # seq:45
+OF_ITERS = 3           # seq:46
+OF_POLY_N = 5          # seq:47
+OF_POLY_SIGMA = 1.2    # seq:48
+SIGMA = 2.0            # seq:49
+
+_handles = {}
+
+
+def handle(device=0):
+    """Process-wide fdn handle for `device` (created on first use)."""
+    h = _handles.get(device)
+    if h is None:
+        h = _handles[device] = _lib.Handle(device)
+    return h
+
+
+def _params(l, w, use_of=True, border_mode=_lib.BORDER_MEAN_PAD, chained=True):
+    return _lib.SweepParams(int(l), int(w), OF_ITERS, OF_POLY_N, OF_POLY_SIGMA, int(border_mode),
+                            int(bool(chained)), int(bool(use_of)))
+
+
+def get_gaussian_kernel(sigma=1):
+    return _lib.gaussian_kernel(sigma)
+
+
+def get_flow(reference, target, l=OF_LEVELS, w=OF_WINDOW_SIZE, prev_flow=None, device=0):
+    """cv2.calcOpticalFlowFarneback(prev=target, next=reference, flow=prev_flow, 0.5, l, w, 3, 5, 1.2,
+    OPTFLOW_USE_INITIAL_FLOW): `prev_flow` is the initial guess and is overwritten in place."""
+    if prev_flow is None:
+        raise ValueError("OPTFLOW_USE_INITIAL_FLOW needs prev_flow (cv2 asserts the same)")
+    return handle(device).farneback(target, reference, prev_flow, l, w, OF_ITERS, OF_POLY_N, OF_POLY_SIGMA,
+                                    _lib.USE_INITIAL_FLOW)
+
+
+get_flow_with_prev_flow = get_flow  # par:65
+
+
+def get_flow_without_prev_flow(reference, target, l=OF_LEVELS, w=OF_WINDOW_SIZE, prev_flow=None, device=0):
+    """par:89-114: flags=0, flow=None."""
+    return handle(device).farneback(target, reference, None, l, w, OF_ITERS, OF_POLY_N, OF_POLY_SIGMA, 0)
+
+
+def warp_slice(reference, flow, device=0):
+    return handle(device).warp(reference, flow)
+
+
+def _filter_axis(vol, axis, kernel, l, w, mean, use_of, border_mode, chained, device):
+    return handle(device).filter_axis(vol, axis, kernel, mean, _params(l, w, use_of, border_mode, chained))
+
+
+def OF_filter_along_Z(vol, kernel, l, w, mean, border_mode=_lib.BORDER_MEAN_PAD, chained=True, device=0):
+    return _filter_axis(vol, 0, kernel, l, w, mean, True, border_mode, chained, device)
+
+
+def OF_filter_along_Y(vol, kernel, l, w, mean, border_mode=_lib.BORDER_MEAN_PAD, chained=True, device=0):
+    return _filter_axis(vol, 1, kernel, l, w, mean, True, border_mode, chained, device)
+
+
+def OF_filter_along_X(vol, kernel, l, w, mean, border_mode=_lib.BORDER_MEAN_PAD, chained=True, device=0):
+    return _filter_axis(vol, 2, kernel, l, w, mean, True, border_mode, chained, device)
+
+
+def no_OF_filter_along_Z(vol, kernel, mean, device=0):
+    return _filter_axis(vol, 0, kernel, 0, OF_WINDOW_SIZE, mean, False, _lib.BORDER_MEAN_PAD, True, device)
+
+
+def no_OF_filter_along_Y(vol, kernel, mean, device=0):
+    return _filter_axis(vol, 1, kernel, 0, OF_WINDOW_SIZE, mean, False, _lib.BORDER_MEAN_PAD, True, device)
+
+
+def no_OF_filter_along_X(vol, kernel, mean, device=0):
+    return _filter_axis(vol, 2, kernel, 0, OF_WINDOW_SIZE, mean, False, _lib.BORDER_MEAN_PAD, True, device)
+
+
+def _as_f32(vol):
+    vol = np.asarray(vol)
+    if vol.ndim != 3:
+        raise ValueError(f"expected a (Z, Y, X) volume, got shape {vol.shape}")
+    return np.ascontiguousarray(vol, dtype=np.float32)
+
+
+def OF_filter(vol, kernel, l, w, border_mode=_lib.BORDER_MEAN_PAD, chained=True, device=0):
+    """seq:419-424: mean = vol.mean(); Z, then Y, then X.  A None entry in `kernel` skips that axis."""
+    vol = _as_f32(vol)
+    mean = vol.mean()  # seq:420, numpy's own f32 mean exactly as the reference takes it
+    return handle(device).filter_3d(vol, kernel, mean, _params(l, w, True, border_mode, chained))
+
+
+def no_OF_filter(vol, kernel, device=0):
+    """seq:426-431."""
+    vol = _as_f32(vol)
+    mean = vol.mean()
+    return handle(device).filter_3d(vol, kernel, mean, _params(0, OF_WINDOW_SIZE, False))
+
+
+class GaussianDenoising:
+    """par:116-295 (-n/--no_OF): wrap-around borders; `filter` leaves the result in
+    `self.filtered_vol`.  The reference's thread pool (`number_of_processes`) has no GPU
+    counterpart: every target slice of a pass is batched into the same kernel launches."""
+
+    use_of = False
+
+    def __init__(self, number_of_processes, vol):
+        self.number_of_processes = number_of_processes
+        self.vol = vol
+        self.filtered_vol = np.zeros_like(vol)
+        self.l, self.w = 0, OF_WINDOW_SIZE
+        self.chained = True
+        self.device = 0
+
+    def filter(self, kernels):
+        p = _params(self.l, self.w, self.use_of, _lib.BORDER_WRAP, self.chained)
+        out = handle(self.device).filter_3d(_as_f32(self.vol), kernels, 0.0, p)
+        # par:131,287: results are stored in arrays of the INPUT dtype
+        self.filtered_vol[...] = out
+        self.vol[...] = self.filtered_vol
+        return None
+
+
+class FlowDenoising(GaussianDenoising):
+    """par:297-373.  `get_flow` selects chained (get_flow_with_prev_flow) or recomputed
+    (get_flow_without_prev_flow) flow exactly like par:442-447; `warp_slice` is accepted for
+    signature compatibility.  Deviation (documented in DESIGN.md): the reference discards its
+    X pass (par:290 + par:520); here `vol` and `filtered_vol` both hold the full Z->Y->X result,
+    as src/flowdenoising_GPU.py:460 returns it."""
+
+    use_of = True
+
+    def __init__(self, number_of_processes, vol, l, w, get_flow=None, warp_slice=None):
+        super().__init__(number_of_processes, vol)
+        self.l, self.w = l, w
+        self.chained = get_flow is not get_flow_without_prev_flow

@@ -1,0 +1,201 @@
+"""GPU parity tests: the HIP path (through the C ABI, via flowdenoising_amd) against the CPU
+oracle on the same seeded inputs, and against the reference-generated goldens.
+
+Tolerances (float32 path, BASELINE.json: "within 1e-4 relative of the sequential reference"):
+  REL_TOL   = 1e-4  max|gpu - oracle| / max|oracle| against the faithful (running-sum) oracle
+  TIGHT_TOL = 2e-6  same metric against the oracle's direct-box-sum mode, which performs the
+                    same arithmetic as the kernels; anything above this is a bug, not rounding.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4
+TIGHT_TOL = 2e-6
+
+
+def _img(rng, H, W, amp=200.0, smooth=2.0):
+    import scipy.ndimage
+    a = scipy.ndimage.gaussian_filter(rng.standard_normal((H, W)), smooth)
+    return (a / np.abs(a).max() * amp).astype(np.float32)
+
+
+def test_gaussian_kernel_matches_reference_golden(fdn):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_kernels.npz"))
+    for i, s in enumerate(g["sigmas"]):
+        k = fdn.get_gaussian_kernel(float(s))
+        assert k.shape == g[f"k{i}"].shape
+        np.testing.assert_allclose(k, g[f"k{i}"], rtol=0, atol=1e-16)
+
+
+def test_warp_bit_exact(fdn, oracle):
+    rng = np.random.default_rng(1)
+    H, W = 37, 53
+    img = _img(rng, H, W)
+    flow = (rng.standard_normal((H, W, 2)) * 3).astype(np.float32)
+    flow[0, 0] = (1 / 64, 0)        # exactly half a quantisation step: round-half-even
+    flow[0, 1] = (3 / 64, -1 / 64)
+    flow[1, 0] = (-100, 100)        # far outside: clamped taps
+    flow[2, 2] = (0, 0)
+    got = fdn.warp_slice(img, flow)
+    want = oracle.warp_slice(img, flow)
+    assert np.array_equal(got, want)
+
+
+def test_warp_zero_and_integer_flow(fdn):
+    rng = np.random.default_rng(2)
+    img = _img(rng, 24, 40)
+    assert np.array_equal(fdn.warp_slice(img, np.zeros((24, 40, 2), np.float32)), img)
+    flow = np.zeros((24, 40, 2), np.float32)
+    flow[..., 0] = 2
+    flow[..., 1] = -1
+    got = fdn.warp_slice(img, flow)
+    yy = np.clip(np.arange(24) - 1, 0, 23)
+    xx = np.clip(np.arange(40) + 2, 0, 39)
+    assert np.array_equal(got, img[yy][:, xx])
+
+
+@pytest.mark.parametrize("shape", [(64, 96), (33, 47), (130, 70)])
+@pytest.mark.parametrize("w", [5, 7, 4])
+def test_farneback_pair(fdn, oracle, shape, w):
+    rng = np.random.default_rng(3)
+    H, W = shape
+    import scipy.ndimage
+    a = _img(rng, H, W)
+    b = scipy.ndimage.shift(a.astype(np.float64), (0.6, -0.4), order=3, mode="nearest").astype(np.float32)
+    b += (rng.standard_normal((H, W)) * 2).astype(np.float32)
+    for init in ("zero", "random"):
+        f0 = np.zeros((H, W, 2), np.float32) if init == "zero" else (rng.standard_normal((H, W, 2)) * 0.5).astype(np.float32)
+        got = fdn.get_flow(b, a, 0, w, f0.copy())
+        tight = oracle.get_flow(b, a, 0, w, f0.copy(), box_mode=oracle.BOX_DIRECT)
+        faithful = oracle.get_flow(b, a, 0, w, f0.copy(), box_mode=oracle.BOX_RUNNING)
+        scale = max(np.abs(faithful).max(), 1.0)
+        assert np.abs(got - tight).max() / scale < TIGHT_TOL, (init, np.abs(got - tight).max())
+        assert np.abs(got - faithful).max() / scale < REL_TOL, (init, np.abs(got - faithful).max())
+    # without initial flow (par:89-114)
+    got = fdn.get_flow_without_prev_flow(b, a, 0, w)
+    want = oracle.calcOpticalFlowFarneback(a, b, None, 0.5, 0, w, 3, 5, 1.2, 0, box_mode=oracle.BOX_DIRECT)
+    assert np.abs(got - want).max() < TIGHT_TOL * max(np.abs(want).max(), 1.0)
+
+
+def test_get_flow_updates_prev_flow_in_place(fdn):
+    rng = np.random.default_rng(4)
+    a, b = _img(rng, 40, 40), _img(rng, 40, 40)
+    f = np.zeros((40, 40, 2), np.float32)
+    out = fdn.get_flow(b, a, 0, 5, f)
+    assert out is f and np.abs(f).max() > 0
+
+
+def test_no_of_filter_matches_reference_golden(fdn):
+    import os
+    n = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_no_of.npz"))
+    ks = [fdn.get_gaussian_kernel(float(s)) for s in n["sigmas"]]
+    got = fdn.no_OF_filter(n["vol"], ks)
+    assert got.dtype == np.float32
+    assert np.array_equal(got, n["out"])
+
+
+def _vol(shape, seed=7):
+    from flowdenoising_amd.synth import make_volume
+    return make_volume(shape, seed=seed, amplitude=100.0)
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_of_filter_single_axis(fdn, oracle, axis):
+    vol = _vol((18, 40, 44))
+    k = fdn.get_gaussian_kernel(1.0)
+    mean = vol.mean()
+    fn = [fdn.OF_filter_along_Z, fdn.OF_filter_along_Y, fdn.OF_filter_along_X][axis]
+    got = fn(vol, k, 0, 5, mean)
+    tight = oracle.filter_along_axis(vol, axis, k, 0, 5, mean, box_mode=oracle.BOX_DIRECT)
+    faithful = oracle.filter_along_axis(vol, axis, k, 0, 5, mean, box_mode=oracle.BOX_RUNNING)
+    assert rel_err(got, tight) < TIGHT_TOL
+    assert rel_err(got, faithful) < REL_TOL
+
+
+def test_of_filter_3d(fdn, oracle):
+    vol = _vol((20, 36, 40), seed=11)
+    ks = [fdn.get_gaussian_kernel(s) for s in (1.0, 1.5, 0.5)]
+    got = fdn.OF_filter(vol, ks, 0, 5)
+    tight = oracle.OF_filter(vol, ks, 0, 5, box_mode=oracle.BOX_DIRECT)
+    faithful = oracle.OF_filter(vol, ks, 0, 5, box_mode=oracle.BOX_RUNNING)
+    assert got.dtype == np.float32 and got.shape == vol.shape
+    assert rel_err(got, tight) < TIGHT_TOL
+    assert rel_err(got, faithful) < REL_TOL
+    # and it is not the plain Gaussian
+    assert rel_err(got, oracle.no_OF_filter(vol, ks)) > 1e-3
+
+
+def test_of_filter_wrap_and_recompute(fdn, oracle):
+    """par's variant: wrap-around neighbours (par:312) and --recompute_flow (par:89-114)."""
+    vol = _vol((10, 34, 38), seed=5)
+    ks = [fdn.get_gaussian_kernel(1.0), None, None]
+    from flowdenoising_amd import _lib
+    got = fdn.OF_filter(vol, ks, 0, 5, border_mode=_lib.BORDER_WRAP, chained=False)
+    want = oracle.OF_filter(vol, ks, 0, 5, border_mode=1, chained=False, box_mode=oracle.BOX_DIRECT)
+    assert rel_err(got, want) < TIGHT_TOL
+
+
+def test_constant_volume(fdn):
+    """SURVEY 8c KAT 5: constant volume v -> v * sum(w) per pass."""
+    vol = np.full((6, 34, 36), 37.5, np.float32)
+    ks = [fdn.get_gaussian_kernel(0.5)] * 3
+    got = fdn.OF_filter(vol, ks, 0, 5)
+    np.testing.assert_allclose(got, 37.5, rtol=1e-6)
+
+
+def test_kernel_size_one_is_identity(fdn):
+    vol = _vol((4, 34, 36))
+    got = fdn.OF_filter(vol, [np.array([1.0]), None, None], 0, 5)
+    assert np.array_equal(got, vol)
+
+
+def test_permute_roundtrip(fdn):
+    from flowdenoising_amd.operators import handle
+    h = handle()
+    rng = np.random.default_rng(0)
+    Z, Y, X = 5, 37, 70
+    a = rng.standard_normal((Z, Y, X)).astype(np.float32)
+    d_in = h.malloc(a.nbytes)
+    d_out = h.malloc(a.nbytes)
+    h.h2d(d_in, a)
+    try:
+        # out[y][z][x]
+        h.permute_dev(d_in, d_out, (Y, Z, X), (X, Y * X, 1))
+        out = np.empty((Y, Z, X), np.float32); h.d2h(out, d_out)
+        assert np.array_equal(out, a.transpose(1, 0, 2))
+        # out[x][z][y]
+        h.permute_dev(d_in, d_out, (X, Z, Y), (1, Y * X, X))
+        out = np.empty((X, Z, Y), np.float32); h.d2h(out, d_out)
+        assert np.array_equal(out, a.transpose(2, 0, 1))
+        # from [x][z][y] back to [z][y][x]
+        h.h2d(d_in, np.ascontiguousarray(a.transpose(2, 0, 1)))
+        h.permute_dev(d_in, d_out, (Z, Y, X), (Y, 1, Z * Y))
+        out = np.empty((Z, Y, X), np.float32); h.d2h(out, d_out)
+        assert np.array_equal(out, a)
+    finally:
+        h.free(d_in); h.free(d_out)
+
+
+def test_mean_dev(fdn):
+    from flowdenoising_amd.operators import handle
+    h = handle()
+    a = _vol((7, 33, 35))
+    d = h.malloc(a.nbytes)
+    h.h2d(d, a)
+    try:
+        m = h.mean_dev(d, a.size)
+    finally:
+        h.free(d)
+    assert abs(float(m) - float(a.astype(np.float64).mean())) <= 1e-6 * abs(float(a.mean()))
+
+
+def test_errors_are_loud(fdn):
+    from flowdenoising_amd._lib import FlowdnError
+    vol = _vol((4, 34, 36))
+    with pytest.raises(FlowdnError):
+        fdn.OF_filter(vol, [np.array([0.5, 0.5]), None, None], 0, 5)  # even kernel (seq:93 assert)
