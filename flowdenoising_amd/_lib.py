@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libflowdn.so")
 USE_INITIAL_FLOW = 4
 BORDER_MEAN_PAD = 0
 BORDER_WRAP = 1
-TIMER_NAMES = ("polyexp", "flow", "warp", "permute", "transfer")
+TIMER_NAMES = ("polyexp", "update_matrices", "update_flow", "warp", "permute", "transfer", "fused")
 
 
 class FlowdnError(RuntimeError):
@@ -130,9 +130,11 @@ class Handle:
         check(self._lib.fdn_enable_timers(self._h, ctypes.c_int(int(on))))
 
     def timers(self, reset=False):
-        out = (ctypes.c_double * len(TIMER_NAMES))()
-        check(self._lib.fdn_get_timers(self._h, out, ctypes.c_int(int(reset))))
-        return dict(zip(TIMER_NAMES, list(out)))
+        """{name: (milliseconds, launches)} measured with HIP events on the handle's stream."""
+        ms = (ctypes.c_double * len(TIMER_NAMES))()
+        cnt = (ctypes.c_longlong * len(TIMER_NAMES))()
+        check(self._lib.fdn_get_timers(self._h, ms, cnt, ctypes.c_int(int(reset))))
+        return {n: (ms[i], cnt[i]) for i, n in enumerate(TIMER_NAMES)}
 
     # -- pair operators ------------------------------------------------------------
     def farneback(self, prev, next, flow, levels, winsize, iters, poly_n, poly_sigma, flags):

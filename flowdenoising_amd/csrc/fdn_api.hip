@@ -118,10 +118,35 @@ struct fdn_ctx {
     hipStream_t stream = nullptr;
     size_t ws_limit = 0;
     DevBuf R, M0, M1, flow, stack, sweep_out, vol_a, vol_b, partials, pair;
+    // timers: event pairs are recorded asynchronously and resolved in fdn_get_timers
     bool timers = false;
-    double tms[FDN_TIMER_COUNT] = {0, 0, 0, 0, 0};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double tms[FDN_TIMER_COUNT] = {};
+    long long tcount[FDN_TIMER_COUNT] = {};
+    struct Stamp { hipEvent_t a, b; int which; };
+    std::vector<Stamp> stamps;        // recorded, not yet resolved
+    std::vector<hipEvent_t> ev_pool;  // free events
 };
+
+static hipEvent_t get_event(fdn_ctx* h)
+{
+    if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+static void resolve_stamps(fdn_ctx* h)
+{
+    if (h->stamps.empty()) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& s : h->stamps) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { h->tms[s.which] += ms; h->tcount[s.which]++; }
+        h->ev_pool.push_back(s.a);
+        h->ev_pool.push_back(s.b);
+    }
+    h->stamps.clear();
+}
 
 static int ensure(fdn_ctx* h, DevBuf& b, size_t bytes)
 {
@@ -138,16 +163,20 @@ static int ensure(fdn_ctx* h, DevBuf& b, size_t bytes)
 }
 
 struct ScopedTimer {
-    fdn_ctx* h; int which;
-    ScopedTimer(fdn_ctx* h_, int w) : h(h_), which(w) { if (h->timers) (void)hipEventRecord(h->ev0, h->stream); }
-    ~ScopedTimer()
+    fdn_ctx* h; int which; hipEvent_t a = nullptr;
+    ScopedTimer(fdn_ctx* h_, int w) : h(h_), which(w)
     {
         if (!h->timers) return;
-        (void)hipEventRecord(h->ev1, h->stream);
-        (void)hipEventSynchronize(h->ev1);
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
-        h->tms[which] += ms;
+        a = get_event(h);
+        (void)hipEventRecord(a, h->stream);
+    }
+    ~ScopedTimer()
+    {
+        if (!a) return;
+        hipEvent_t b = get_event(h);
+        (void)hipEventRecord(b, h->stream);
+        h->stamps.push_back({a, b, which});
+        if (h->stamps.size() > 4096) resolve_stamps(h);
     }
 };
 
@@ -181,10 +210,14 @@ static int effective_levels(int levels, int H, int W)
 static void run_iterations(fdn_ctx* h, const float* Rstack, float* flow, float* M0, float* M1, PairBatch pb,
                            int H, int W, int winsize, int iters)
 {
-    launch_update_matrices(Rstack, flow, M0, pb, H, W, h->stream);
+    {
+        ScopedTimer t(h, FDN_TIMER_UPDATE_MATRICES);
+        launch_update_matrices(Rstack, flow, M0, pb, H, W, h->stream);
+    }
     float* cur = M0; float* nxt = M1;
     for (int it = 0; it < iters; it++) {
         bool update = it < iters - 1;
+        ScopedTimer t(h, FDN_TIMER_UPDATE_FLOW);
         launch_update_flow(Rstack, cur, update ? nxt : nullptr, flow, pb, H, W, winsize, h->stream);
         std::swap(cur, nxt);
     }
@@ -244,10 +277,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
                 int d = side == 0 ? -(step + 1) : (step + 1); // nearest neighbour first (seq:95,110)
                 PairBatch pb{n, r + c0, d};
                 if (!p->chained && step > 0) launch_fill(flow, 0.f, (size_t)n * HW * 2, st);
-                {
-                    ScopedTimer t(h, FDN_TIMER_FLOW);
-                    run_iterations(h, R, flow, M0, M1, pb, H, W, p->winsize, p->iters);
-                }
+                run_iterations(h, R, flow, M0, M1, pb, H, W, p->winsize, p->iters);
                 {
                     ScopedTimer t(h, FDN_TIMER_WARP);
                     launch_warp_accumulate(stack, flow, acc, pb, H, W, kernel[r + d], st);
@@ -363,8 +393,6 @@ FDN_API int fdn_create(int device, fdn_handle* out)
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
     h->stream = h->own_stream;
-    (void)hipEventCreate(&h->ev0);
-    (void)hipEventCreate(&h->ev1);
     *out = h;
     return 0;
 }
@@ -376,8 +404,8 @@ FDN_API int fdn_destroy(fdn_handle h)
     (void)hipStreamSynchronize(h->stream);
     DevBuf* bufs[] = {&h->R, &h->M0, &h->M1, &h->flow, &h->stack, &h->sweep_out, &h->vol_a, &h->vol_b, &h->partials, &h->pair};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    resolve_stamps(h);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return 0;
@@ -491,10 +519,7 @@ FDN_API int fdn_farneback(fdn_handle h, const float* prev, const float* next, fl
         ScopedTimer t(h, FDN_TIMER_POLYEXP);
         launch_blur3_polyexp(img, R, 2, H, W, pc, st);
     }
-    {
-        ScopedTimer t(h, FDN_TIMER_FLOW);
-        run_iterations(h, R, flow, M0, M1, PairBatch{1, 0, 1}, H, W, winsize, iters);
-    }
+    run_iterations(h, R, flow, M0, M1, PairBatch{1, 0, 1}, H, W, winsize, iters);
     FDN_HIP(hipGetLastError());
     {
         ScopedTimer t(h, FDN_TIMER_TRANSFER);
@@ -649,11 +674,13 @@ FDN_API int fdn_enable_timers(fdn_handle h, int on)
     h->timers = on != 0;
     return 0;
 }
-FDN_API int fdn_get_timers(fdn_handle h, double* ms_out, int reset)
+FDN_API int fdn_get_timers(fdn_handle h, double* ms_out, long long* count_out, int reset)
 {
     FDN_ENTER(h);
+    resolve_stamps(h);
     if (ms_out) for (int i = 0; i < FDN_TIMER_COUNT; i++) ms_out[i] = h->tms[i];
-    if (reset) for (int i = 0; i < FDN_TIMER_COUNT; i++) h->tms[i] = 0;
+    if (count_out) for (int i = 0; i < FDN_TIMER_COUNT; i++) count_out[i] = h->tcount[i];
+    if (reset) for (int i = 0; i < FDN_TIMER_COUNT; i++) { h->tms[i] = 0; h->tcount[i] = 0; }
     return 0;
 }
 

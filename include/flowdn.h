@@ -135,14 +135,20 @@ int fdn_permute_dev(fdn_handle h, const float* d_in, float* d_out, int A, int B,
 
 /* ---- timers (the taxonomy of gpu:47-53: OF estimation / warping+convolution /
  *      transfers) ---------------------------------------------------------------------- */
-#define FDN_TIMER_POLYEXP 0
-#define FDN_TIMER_FLOW 1
-#define FDN_TIMER_WARP 2
-#define FDN_TIMER_PERMUTE 3
-#define FDN_TIMER_TRANSFER 4
-#define FDN_TIMER_COUNT 5
+#define FDN_TIMER_POLYEXP 0          /* blur + polynomial expansion, once per slice per pass   */
+#define FDN_TIMER_UPDATE_MATRICES 1  /* initial FarnebackUpdateMatrices of a chain step         */
+#define FDN_TIMER_UPDATE_FLOW 2      /* box filter + 2x2 solve (+ matrix refresh), per iteration */
+#define FDN_TIMER_WARP 3             /* warp + accumulate (and the no-OF taps)                  */
+#define FDN_TIMER_PERMUTE 4          /* slab re-orientation / halo fill                         */
+#define FDN_TIMER_TRANSFER 5         /* H2D / D2H                                               */
+#define FDN_TIMER_FUSED 6            /* fused Farneback chain-step kernel (fast path)           */
+#define FDN_TIMER_COUNT 7
+/* HIP-event timing of the phases above on the handle's stream.  Event pairs are recorded
+ * asynchronously (no host sync inside the timed work) and resolved by fdn_get_timers, which
+ * returns accumulated milliseconds and the number of timed launches per category. */
 int fdn_enable_timers(fdn_handle h, int on);
-int fdn_get_timers(fdn_handle h, double* ms_out /* FDN_TIMER_COUNT */, int reset);
+int fdn_get_timers(fdn_handle h, double* ms_out /* FDN_TIMER_COUNT */,
+                   long long* count_out /* FDN_TIMER_COUNT */, int reset);
 
 /* library/version string, e.g. "flowdn 0.1 gfx950" */
 const char* fdn_version(void);

@@ -759,11 +759,16 @@ static void neighbour(const float* vol, int Z, int Y, int X, int axis, int n, in
     else get_slice(vol, Z, Y, X, axis, q, out);
 }
 
-FDO_EXPORT void fdo_filter_axis(const float* vol, float* out, int Z, int Y, int X, int axis,
-                                const double* kernel, int K, float mean, const fdo_sweep_params* sp)
+/* Targets s0 <= s < s1 only (the other output slices are left untouched): used to time a
+ * bounded sample of a large volume (bench.py cpu_baseline). */
+FDO_EXPORT void fdo_filter_axis_range(const float* vol, float* out, int Z, int Y, int X, int axis,
+                                      const double* kernel, int K, float mean, const fdo_sweep_params* sp,
+                                      int s0, int s1)
 {
     int n, H, W;
     slice_dims(Z, Y, X, axis, &n, &H, &W);
+    if (s0 < 0) s0 = 0;
+    if (s1 > n) s1 = n;
     size_t npx = (size_t)H * W;
     fdo_fb_params fb = {sp->levels, sp->winsize, 3, 5, 1.2, sp->chained ? 4 : 0, sp->box_mode};
     int nt = sp->nthreads > 0 ? sp->nthreads : 1;
@@ -776,7 +781,7 @@ FDO_EXPORT void fdo_filter_axis(const float* vol, float* out, int Z, int Y, int 
         float* tmp = (float*)malloc(npx * sizeof(float));
         float* flow = (float*)malloc(npx * 2 * sizeof(float));
 #pragma omp for schedule(static)
-        for (int s = 0; s < n; s++) {
+        for (int s = s0; s < s1; s++) {
             get_slice(vol, Z, Y, X, axis, s, target);
             for (size_t j = 0; j < npx; j++) tmp[j] = 0.f;
             if (!sp->use_of) { /* seq:184-185: taps in index order 0..K-1 */
@@ -808,6 +813,14 @@ FDO_EXPORT void fdo_filter_axis(const float* vol, float* out, int Z, int Y, int 
         }
         free(target); free(ref); free(warped); free(tmp); free(flow);
     }
+}
+
+FDO_EXPORT void fdo_filter_axis(const float* vol, float* out, int Z, int Y, int X, int axis,
+                                const double* kernel, int K, float mean, const fdo_sweep_params* sp)
+{
+    int n, H, W;
+    slice_dims(Z, Y, X, axis, &n, &H, &W);
+    fdo_filter_axis_range(vol, out, Z, Y, X, axis, kernel, K, mean, sp, 0, n);
 }
 
 /* a-8 OF_filter (seq:419-424) / a-9 no_OF_filter (seq:426-431): one mean, Z then Y then X.

@@ -141,6 +141,20 @@ def filter_along_axis(vol, axis, kernel, l, w, mean, use_of=True, border_mode=0,
     return out
 
 
+def filter_axis_range(vol, axis, kernel, l, w, mean, s0, s1, use_of=True, border_mode=0, chained=True,
+                      box_mode=BOX_RUNNING, nthreads=1):
+    """Like filter_along_axis but only targets s0 <= s < s1 are computed (others are zero)."""
+    vol = _f32(vol)
+    Z, Y, X = vol.shape
+    kernel = np.ascontiguousarray(kernel, dtype=np.float64)
+    out = np.zeros_like(vol)
+    sp = _sweep_params(l, w, border_mode, chained, use_of, box_mode, nthreads)
+    lib().fdo_filter_axis_range(_p(vol), _p(out), ctypes.c_int(Z), ctypes.c_int(Y), ctypes.c_int(X),
+                                ctypes.c_int(axis), _p(kernel), ctypes.c_int(kernel.size),
+                                ctypes.c_float(float(mean)), ctypes.byref(sp), ctypes.c_int(s0), ctypes.c_int(s1))
+    return out
+
+
 def OF_filter_along_Z(vol, kernel, l, w, mean, **kw):
     return filter_along_axis(vol, 0, kernel, l, w, mean, **kw)
 
