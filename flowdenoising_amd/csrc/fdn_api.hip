@@ -185,7 +185,7 @@ static int check_params(const fdn_sweep_params* p, int K)
     if (!p) return fail("params is NULL");
     if (K < 1 || (K & 1) == 0) return fail("kernel.size must be odd (seq:93), got %d", K);
     if (p->use_of) {
-        if (p->winsize < 1) return fail("winsize must be >= 1, got %d", p->winsize);
+        if (p->winsize < 1 || p->winsize > 49) return fail("winsize must be in 1..49, got %d", p->winsize);
         if (p->poly_n < 1 || p->poly_n > 7) return fail("poly_n must be in 1..7, got %d", p->poly_n);
         if (p->iters < 0) return fail("iters must be >= 0");
         if (p->levels < 0) return fail("levels must be >= 0");

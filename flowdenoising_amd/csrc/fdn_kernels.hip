@@ -199,14 +199,21 @@ void launch_update_matrices(const float* Rstack, const float* flow, float* M, Pa
 }
 
 // ---------------------------------------------------------------------------------
-// FarnebackUpdateFlow_Blur: (2m+1)^2 box sum of M (replicate borders, f64 like OpenCV's
-// vsum / g11..h2, as DIRECT window sums rather than running sums), 2x2 solve in f64,
-// then optionally the matrix refresh for the next iteration.
-// Block 256 threads, tile 32 x 16, dynamic LDS: M tile with halo m (f32) + vertical
-// sums (f64).
+// FarnebackUpdateFlow_Blur, column-streaming form.
+//
+// OpenCV keeps, per column and channel, a vertical RUNNING sum in f64 that is fed by f32
+// row differences: vsum += (float)(M[y+m] - M[y-m-1]).  The f32 rounding of those
+// differences random-walks down the image and, through the ill-conditioned 2x2 solve,
+// moves the flow by up to ~1e-4 relative on ordinary data -- so a tile-local box sum
+// cannot meet the 1e-4 parity bar.  Here one wave owns a band of 64 columns and marches
+// down the rows carrying vsum[5] in registers, which reproduces that arithmetic exactly.
+// The horizontal (2m+1)-sum is taken across lanes with wave shuffles in f64 (OpenCV's own
+// horizontal running sum is f64 too; the two differ by ~1e-16 relative).
+//   band b covers columns [b*BW - m, b*BW - m + 64), BW = 64 - 2m; lanes [m, 64-m) own outputs;
+//   out-of-image columns act as replicas of the clamped column (BORDER_REPLICATE of vsum).
+// Rows may be split into segments for parallelism on small batches: a segment first
+// replays the cheap vertical recurrence from row 0 so that its running sum is the same.
 // ---------------------------------------------------------------------------------
-constexpr int UF_TW = 32, UF_TH = 16;
-
 static __device__ __forceinline__ float2 solve_flow(const double a[5], double scale)
 {
     double g11 = a[0] * scale, g12 = a[1] * scale, g22 = a[2] * scale, h1 = a[3] * scale, h2 = a[4] * scale;
@@ -217,64 +224,72 @@ static __device__ __forceinline__ float2 solve_flow(const double a[5], double sc
     return f;
 }
 
-__global__ __launch_bounds__(256) void k_update_flow(const float* __restrict__ Rstack, const float* __restrict__ Min_base,
-                                                     float* __restrict__ Mout_base, float* __restrict__ flow_base,
-                                                     PairBatch pb, int H, int W, int m, double scale)
+// vsum before row 0: M[0]*(m+2) (an f32 product) + rows 1..m-1 (clamped)
+static __device__ __forceinline__ void vsum_init(const float* __restrict__ Mc, size_t HW, int H, int W, int xc, int m, double vs[5])
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int LW = UF_TW + 2 * m, LH = UF_TH + 2 * m;
-    double* sV = (double*)smem;                               // [5][UF_TH][LW]
-    float* sM = (float*)(smem + (size_t)5 * UF_TH * LW * 8);  // [5][LH][LW]
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const float* p = Mc + c * HW + xc;
+        double v = (double)(p[0] * (float)(m + 2));
+        for (int y = 1; y < m; y++) v += (double)p[(size_t)(y < H - 1 ? y : H - 1) * W];
+        vs[c] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_update_flow_scan(const float* __restrict__ Rstack, const float* __restrict__ Min_base,
+                                                          float* __restrict__ Mout_base, float* __restrict__ flow_base,
+                                                          PairBatch pb, int H, int W, int m, double scale,
+                                                          int nbands, int rows_per_seg)
+{
+    const int lane = threadIdx.x & 63;
+    const int band = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (band >= nbands) return;               // whole wave leaves; no block-level sync below
+    const int BW = 64 - 2 * m;
+    const int x = band * BW - m + lane;
+    const int xc = clampi(x, 0, W - 1);
     const size_t HW = (size_t)H * W;
     const int b = blockIdx.z;
     const float* Min = Min_base + (size_t)b * 5 * HW;
-    const int x0 = blockIdx.x * UF_TW, y0 = blockIdx.y * UF_TH;
+    const int ys = blockIdx.y * rows_per_seg;
+    const int ye = ys + rows_per_seg < H ? ys + rows_per_seg : H;
 
-    for (int idx = threadIdx.x; idx < LW * LH; idx += 256) {
-        int ty = idx / LW, tx = idx - ty * LW;
-        int cy = clampi(y0 - m + ty, 0, H - 1), cx = clampi(x0 - m + tx, 0, W - 1);
-        size_t o = (size_t)cy * W + cx;
+    double vs[5];
+    vsum_init(Min, HW, H, W, xc, m, vs);
+    for (int y = 0; y < ys; y++) { // replay of the vertical recurrence for rows above the segment
+        const float* p1 = Min + (size_t)(y + m < H - 1 ? y + m : H - 1) * W + xc;
+        const float* p0 = Min + (size_t)(y - m - 1 > 0 ? y - m - 1 : 0) * W + xc;
 #pragma unroll
-        for (int c = 0; c < 5; c++) sM[(c * LH + ty) * LW + tx] = Min[c * HW + o];
+        for (int c = 0; c < 5; c++) vs[c] += (double)(p1[c * HW] - p0[c * HW]);
     }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < LW * UF_TH; idx += 256) {
-        int ry = idx / LW, tx = idx - ry * LW;
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-            const float* p = sM + (c * LH + ry) * LW + tx;
-            double s = 0;
-            for (int j = 0; j <= 2 * m; j++) s += (double)p[j * LW];
-            sV[(c * UF_TH + ry) * LW + tx] = s;
-        }
-    }
-    __syncthreads();
+    const bool owner = lane >= m && lane < 64 - m && x < W;
     const float* R0 = Rstack + (size_t)(pb.t0 + b) * 5 * HW;
     const float* R1 = Rstack + (size_t)(pb.t0 + b + pb.d) * 5 * HW;
     float2* flow = (float2*)flow_base + (size_t)b * HW;
     float* Mout = Mout_base ? Mout_base + (size_t)b * 5 * HW : nullptr;
-    for (int idx = threadIdx.x; idx < UF_TW * UF_TH; idx += 256) {
-        int ry = idx / UF_TW, ox = idx - ry * UF_TW;
-        int x = x0 + ox, y = y0 + ry;
-        if (x >= W || y >= H) continue;
+
+    for (int y = ys; y < ye; y++) {
+        const float* p1 = Min + (size_t)(y + m < H - 1 ? y + m : H - 1) * W + xc;
+        const float* p0 = Min + (size_t)(y - m - 1 > 0 ? y - m - 1 : 0) * W + xc;
         double a[5];
 #pragma unroll
         for (int c = 0; c < 5; c++) {
-            const double* p = sV + (c * UF_TH + ry) * LW + ox;
+            vs[c] += (double)(p1[c * HW] - p0[c * HW]);
             double s = 0;
-            for (int i = 0; i <= 2 * m; i++) s += p[i];
+            for (int j = -m; j <= m; j++) s += __shfl(vs[c], clampi(lane + j, 0, 63), 64);
             a[c] = s;
         }
-        float2 f = solve_flow(a, scale);
-        size_t o = (size_t)y * W + x;
-        flow[o] = f;
-        if (Mout) {
-            float r0[5], mm[5];
+        if (owner) {
+            float2 f = solve_flow(a, scale);
+            size_t o = (size_t)y * W + x;
+            flow[o] = f;
+            if (Mout) {
+                float r0[5], mm[5];
 #pragma unroll
-            for (int c = 0; c < 5; c++) r0[c] = R0[c * HW + o];
-            compute_M(r0, R1, HW, H, W, x, y, f.x, f.y, mm);
+                for (int c = 0; c < 5; c++) r0[c] = R0[c * HW + o];
+                compute_M(r0, R1, HW, H, W, x, y, f.x, f.y, mm);
 #pragma unroll
-            for (int c = 0; c < 5; c++) Mout[c * HW + o] = mm[c];
+                for (int c = 0; c < 5; c++) Mout[c * HW + o] = mm[c];
+            }
         }
     }
 }
@@ -285,10 +300,19 @@ void launch_update_flow(const float* Rstack, const float* Min, float* Mout, floa
     if (pb.npairs <= 0) return;
     int m = winsize / 2;
     double scale = 1. / ((double)winsize * winsize);
-    int LW = UF_TW + 2 * m, LH = UF_TH + 2 * m;
-    size_t lds = (size_t)5 * UF_TH * LW * 8 + (size_t)5 * LH * LW * 4;
-    dim3 grid((W + UF_TW - 1) / UF_TW, (H + UF_TH - 1) / UF_TH, pb.npairs);
-    hipLaunchKernelGGL(k_update_flow, grid, dim3(256), lds, st, Rstack, Min, Mout, flow, pb, H, W, m, scale);
+    int BW = 64 - 2 * m;
+    int nbands = (W + BW - 1) / BW;
+    // enough waves to fill 256 CUs x 8 waves; otherwise split rows (each segment replays the
+    // vertical recurrence above it, so keep segments few)
+    long waves = (long)nbands * pb.npairs;
+    int nseg = 1;
+    if (waves < 4096) nseg = (int)((4096 + waves - 1) / waves);
+    int max_seg = (H + 31) / 32;
+    if (nseg > max_seg) nseg = max_seg;
+    int rows_per_seg = (H + nseg - 1) / nseg;
+    nseg = (H + rows_per_seg - 1) / rows_per_seg;
+    dim3 grid((nbands + 3) / 4, nseg, pb.npairs);
+    hipLaunchKernelGGL(k_update_flow_scan, grid, dim3(256), 0, st, Rstack, Min, Mout, flow, pb, H, W, m, scale, nbands, rows_per_seg);
 }
 
 // ---------------------------------------------------------------------------------

@@ -1,10 +1,11 @@
 """GPU parity tests: the HIP path (through the C ABI, via flowdenoising_amd) against the CPU
 oracle on the same seeded inputs, and against the reference-generated goldens.
 
-Tolerances (float32 path, BASELINE.json: "within 1e-4 relative of the sequential reference"):
-  REL_TOL   = 1e-4  max|gpu - oracle| / max|oracle| against the faithful (running-sum) oracle
-  TIGHT_TOL = 2e-6  same metric against the oracle's direct-box-sum mode, which performs the
-                    same arithmetic as the kernels; anything above this is a bug, not rounding.
+Tolerance (float32 path).  BASELINE.json asks for "within 1e-4 relative of the sequential
+reference"; the kernels reproduce the oracle's arithmetic operation by operation (including
+OpenCV's f32-fed vertical running sums), so the tests hold them to a much tighter bar:
+  TIGHT_TOL = 2e-6  max|gpu - oracle| / max|oracle| (flows: / max(|flow|, 1 px)).
+The only deliberate differences are f64 summation orders (horizontal box sum, mean), ~1e-16.
 """
 import numpy as np
 import pytest
@@ -13,7 +14,6 @@ from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
 
-REL_TOL = 1e-4
 TIGHT_TOL = 2e-6
 
 
@@ -71,14 +71,12 @@ def test_farneback_pair(fdn, oracle, shape, w):
     for init in ("zero", "random"):
         f0 = np.zeros((H, W, 2), np.float32) if init == "zero" else (rng.standard_normal((H, W, 2)) * 0.5).astype(np.float32)
         got = fdn.get_flow(b, a, 0, w, f0.copy())
-        tight = oracle.get_flow(b, a, 0, w, f0.copy(), box_mode=oracle.BOX_DIRECT)
-        faithful = oracle.get_flow(b, a, 0, w, f0.copy(), box_mode=oracle.BOX_RUNNING)
-        scale = max(np.abs(faithful).max(), 1.0)
-        assert np.abs(got - tight).max() / scale < TIGHT_TOL, (init, np.abs(got - tight).max())
-        assert np.abs(got - faithful).max() / scale < REL_TOL, (init, np.abs(got - faithful).max())
+        want = oracle.get_flow(b, a, 0, w, f0.copy())
+        scale = max(np.abs(want).max(), 1.0)
+        assert np.abs(got - want).max() / scale < TIGHT_TOL, (init, np.abs(got - want).max())
     # without initial flow (par:89-114)
     got = fdn.get_flow_without_prev_flow(b, a, 0, w)
-    want = oracle.calcOpticalFlowFarneback(a, b, None, 0.5, 0, w, 3, 5, 1.2, 0, box_mode=oracle.BOX_DIRECT)
+    want = oracle.calcOpticalFlowFarneback(a, b, None, 0.5, 0, w, 3, 5, 1.2, 0)
     assert np.abs(got - want).max() < TIGHT_TOL * max(np.abs(want).max(), 1.0)
 
 
@@ -111,21 +109,17 @@ def test_of_filter_single_axis(fdn, oracle, axis):
     mean = vol.mean()
     fn = [fdn.OF_filter_along_Z, fdn.OF_filter_along_Y, fdn.OF_filter_along_X][axis]
     got = fn(vol, k, 0, 5, mean)
-    tight = oracle.filter_along_axis(vol, axis, k, 0, 5, mean, box_mode=oracle.BOX_DIRECT)
-    faithful = oracle.filter_along_axis(vol, axis, k, 0, 5, mean, box_mode=oracle.BOX_RUNNING)
-    assert rel_err(got, tight) < TIGHT_TOL
-    assert rel_err(got, faithful) < REL_TOL
+    want = oracle.filter_along_axis(vol, axis, k, 0, 5, mean)
+    assert rel_err(got, want) < TIGHT_TOL
 
 
 def test_of_filter_3d(fdn, oracle):
     vol = _vol((20, 36, 40), seed=11)
     ks = [fdn.get_gaussian_kernel(s) for s in (1.0, 1.5, 0.5)]
     got = fdn.OF_filter(vol, ks, 0, 5)
-    tight = oracle.OF_filter(vol, ks, 0, 5, box_mode=oracle.BOX_DIRECT)
-    faithful = oracle.OF_filter(vol, ks, 0, 5, box_mode=oracle.BOX_RUNNING)
+    want = oracle.OF_filter(vol, ks, 0, 5)
     assert got.dtype == np.float32 and got.shape == vol.shape
-    assert rel_err(got, tight) < TIGHT_TOL
-    assert rel_err(got, faithful) < REL_TOL
+    assert rel_err(got, want) < TIGHT_TOL
     # and it is not the plain Gaussian
     assert rel_err(got, oracle.no_OF_filter(vol, ks)) > 1e-3
 
@@ -136,7 +130,7 @@ def test_of_filter_wrap_and_recompute(fdn, oracle):
     ks = [fdn.get_gaussian_kernel(1.0), None, None]
     from flowdenoising_amd import _lib
     got = fdn.OF_filter(vol, ks, 0, 5, border_mode=_lib.BORDER_WRAP, chained=False)
-    want = oracle.OF_filter(vol, ks, 0, 5, border_mode=1, chained=False, box_mode=oracle.BOX_DIRECT)
+    want = oracle.OF_filter(vol, ks, 0, 5, border_mode=1, chained=False)
     assert rel_err(got, want) < TIGHT_TOL
 
 
