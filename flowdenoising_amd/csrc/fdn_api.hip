@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <string>
@@ -250,8 +251,10 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
         ScopedTimer t(h, FDN_TIMER_POLYEXP);
         launch_blur3_polyexp(stack, (float*)h->R.p, nstack, H, W, pc, st);
     }
-    // targets per batch, bounded by the workspace limit: flow 8 B + two M sets 40 B per pixel
-    size_t per_target = HW * (8 + 40);
+    const bool fused = fused_supported(p->winsize, p->iters, H, W) && !getenv("FDN_FORCE_STAGED");
+    // targets per batch, bounded by the workspace limit.  fused: two flow buffers (16 B/px);
+    // staged: flow 8 B + two M sets 40 B per pixel
+    size_t per_target = HW * (fused ? 16 : 48);
     size_t budget = h->ws_limit;
     if (!budget) {
         size_t fre = 0, tot = 0;
@@ -260,10 +263,16 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
         budget = (fre + have) / 10 * 8;
     }
     int C = (int)std::min<size_t>((size_t)S, std::max<size_t>(1, budget / per_target));
-    if (ensure(h, h->flow, (size_t)C * HW * 8)) return -1;
-    if (ensure(h, h->M0, (size_t)C * HW * 20)) return -1;
-    if (ensure(h, h->M1, (size_t)C * HW * 20)) return -1;
-    float* R = (float*)h->R.p; float* flow = (float*)h->flow.p;
+    float* R = (float*)h->R.p;
+    if (fused) {
+        if (ensure(h, h->flow, (size_t)C * HW * 16)) return -1;
+    } else {
+        if (ensure(h, h->flow, (size_t)C * HW * 8)) return -1;
+        if (ensure(h, h->M0, (size_t)C * HW * 20)) return -1;
+        if (ensure(h, h->M1, (size_t)C * HW * 20)) return -1;
+    }
+    float* flow = (float*)h->flow.p;
+    float* flowB = flow + (size_t)C * HW * 2; // fused only
     float* M0 = (float*)h->M0.p; float* M1 = (float*)h->M1.p;
 
     for (int c0 = 0; c0 < S; c0 += C) {
@@ -272,9 +281,22 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
         launch_fill(acc, 0.f, (size_t)n * HW, st);
         for (int side = 0; side < 2; side++) {
             if (side == 1) launch_axpy_slices(stack, acc, PairBatch{n, r + c0, 0}, H, W, kernel[r], st); // seq:108
+            if (fused) {
+                const float* fin = nullptr;          // seq:94,109: the chain restarts from zero flow
+                float* fout = flow;
+                for (int step = 0; step < r; step++) {
+                    int d = side == 0 ? -(step + 1) : (step + 1); // nearest neighbour first (seq:95,110)
+                    bool keep = p->chained && step + 1 < r;       // the next step is seeded with this flow (seq:98)
+                    ScopedTimer t(h, FDN_TIMER_FUSED);
+                    launch_farneback_fused(R, stack, fin, keep ? fout : nullptr, acc, PairBatch{n, r + c0, d}, H, W,
+                                           p->winsize, p->iters, kernel[r + d], st);
+                    if (keep) { fin = fout; fout = fout == flow ? flowB : flow; }
+                }
+                continue;
+            }
             launch_fill(flow, 0.f, (size_t)n * HW * 2, st);                                              // seq:94,109
             for (int step = 0; step < r; step++) {
-                int d = side == 0 ? -(step + 1) : (step + 1); // nearest neighbour first (seq:95,110)
+                int d = side == 0 ? -(step + 1) : (step + 1);
                 PairBatch pb{n, r + c0, d};
                 if (!p->chained && step > 0) launch_fill(flow, 0.f, (size_t)n * HW * 2, st);
                 run_iterations(h, R, flow, M0, M1, pb, H, W, p->winsize, p->iters);

@@ -56,6 +56,15 @@ void launch_axpy_slices(const float* stack, float* acc, PairBatch pb, int H, int
 // dst(y,x) = remap(src, flow)  single image (fdn_warp)
 void launch_warp(const float* src, const float* flow, float* dst, int H, int W, hipStream_t st);
 
+// Fused chain step (fdn_fused.hip): for every pair of the batch, the whole level-0 Farneback
+// (initial matrices + iters x [box filter, solve, refresh]) seeded by flow_in (NULL = zero
+// flow), then acc += weight * remap(stack[n], flow); flow_out (NULL = not needed) receives
+// the final flow for the next chain step.  flow_in and flow_out must be different buffers.
+bool fused_supported(int winsize, int iters, int H, int W);
+void launch_farneback_fused(const float* Rstack, const float* stack, const float* flow_in, float* flow_out,
+                            float* acc, PairBatch pb, int H, int W, int winsize, int iters, double weight,
+                            hipStream_t st);
+
 void launch_fill(float* dst, float value, size_t count, hipStream_t st);
 void launch_permute(const float* in, float* out, int A, int B, int C, int64_t sa, int64_t sb,
                     int64_t sc, hipStream_t st);
