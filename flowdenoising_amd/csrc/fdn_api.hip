@@ -240,6 +240,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
         FDN_HIP(hipGetLastError());
         return 0;
     }
+    if (H < 2 || W < 2) return fail("optical flow needs images of at least 2x2 pixels, got %dx%d", W, H);
     if (effective_levels(p->levels, H, W) > 0)
         return fail("levels > 0 on %dx%d images needs the pyramid path, which this build does not have yet", W, H);
 
@@ -512,7 +513,7 @@ FDN_API int fdn_farneback(fdn_handle h, const float* prev, const float* next, fl
 {
     FDN_ENTER(h);
     if (!prev || !next || !flow_io) return fail("NULL image/flow pointer");
-    if (H <= 0 || W <= 0) return fail("bad image dims");
+    if (H < 2 || W < 2) return fail("optical flow needs images of at least 2x2 pixels, got %dx%d", W, H);
     if (flags & ~FDN_USE_INITIAL_FLOW) return fail("unsupported flags 0x%x (only OPTFLOW_USE_INITIAL_FLOW)", flags);
     fdn_sweep_params p{levels, winsize, iters, poly_n, poly_sigma, 0, 1, 1};
     if (check_params(&p, 1)) return -1;

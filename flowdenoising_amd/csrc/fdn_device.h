@@ -20,58 +20,79 @@ static __device__ __forceinline__ int reflect101(int p, int len)
 // ---------------------------------------------------------------------------------
 // FarnebackUpdateMatrices for one pixel.  r0[5]: R0 at (x,y); R1: planar neighbour
 // expansion (gathered bilinearly at (x+dx, y+dy), exact f32 weights, no quantisation).
+// Branch-free so that several instances interleave in one basic block: the gather always
+// runs at a clamped position and the out-of-image case is a select; the 5-pixel border
+// damping is always multiplied in (it is exactly 1.0f in the interior).  Values are
+// bit-identical to the branching CPU form.  Needs H >= 2 and W >= 2.
+//   bxx = border[x]-factor product for this column, ((x<5 ? b[x] : 1) * (x>=W-5 ? b[W-1-x] : 1))
 // ---------------------------------------------------------------------------------
-static __device__ __forceinline__ void compute_M(const float r0[5], const float* __restrict__ R1, size_t HW,
-                                                 int H, int W, int x, int y, float dx, float dy, float m[5])
+static __device__ __forceinline__ float border_factor(int i, int n)
 {
-    float fx = (float)x + dx, fy = (float)y + dy;
-    float flx = floorf(fx), fly = floorf(fy);
-    int x1 = (int)flx, y1 = (int)fly;
-    fx -= flx; fy -= fly;
-    float r2, r3, r4, r5, r6;
-    if ((unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1)) {
-        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        // the two taps of a row are adjacent in a plane: one 8-byte (dword-aligned) load each
-        const float* p = R1 + (size_t)y1 * W + x1;
-        float2u t0, t1;
-        t0 = *(const float2u*)p; t1 = *(const float2u*)(p + W); p += HW;
-        r2 = a00 * t0.a + a01 * t0.b + a10 * t1.a + a11 * t1.b;
-        t0 = *(const float2u*)p; t1 = *(const float2u*)(p + W); p += HW;
-        r3 = a00 * t0.a + a01 * t0.b + a10 * t1.a + a11 * t1.b;
-        t0 = *(const float2u*)p; t1 = *(const float2u*)(p + W); p += HW;
-        r4 = a00 * t0.a + a01 * t0.b + a10 * t1.a + a11 * t1.b;
-        t0 = *(const float2u*)p; t1 = *(const float2u*)(p + W); p += HW;
-        r5 = a00 * t0.a + a01 * t0.b + a10 * t1.a + a11 * t1.b;
-        t0 = *(const float2u*)p; t1 = *(const float2u*)(p + W);
-        r6 = a00 * t0.a + a01 * t0.b + a10 * t1.a + a11 * t1.b;
-        r4 = (r0[2] + r4) * 0.5f;
-        r5 = (r0[3] + r5) * 0.5f;
-        r6 = (r0[4] + r6) * 0.25f;
-    } else {
-        r2 = r3 = 0.f;
-        r4 = r0[2];
-        r5 = r0[3];
-        r6 = r0[4] * 0.5f;
+    // border[] = {0.14, 0.14, 0.4472, 0.4472, 0.4472}; product of the near-edge and far-edge factors
+    float b0 = i < 5 ? (i < 2 ? 0.14f : 0.4472f) : 1.f;
+    float b1 = i >= n - 5 ? (n - i - 1 < 2 ? 0.14f : 0.4472f) : 1.f;
+    return b0 * b1;
+}
+
+struct GatherTaps { float2u t0[5], t1[5]; };
+
+// issue the ten 8-byte loads of the bilinear gather (two adjacent taps per row per plane)
+static __device__ __forceinline__ void gather_R1(const float* __restrict__ R1, size_t HW, int H, int W,
+                                                 int x1, int y1, GatherTaps& g)
+{
+    const float* p = R1 + (size_t)clampi(y1, 0, H - 2) * W + clampi(x1, 0, W - 2);
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        g.t0[c] = *(const float2u*)(p + c * HW);
+        g.t1[c] = *(const float2u*)(p + c * HW + W);
     }
+}
+
+static __device__ __forceinline__ void flow_target(int x, int y, float dx, float dy, int& x1, int& y1, float& fx, float& fy)
+{
+    fx = (float)x + dx; fy = (float)y + dy;
+    float flx = floorf(fx), fly = floorf(fy);
+    x1 = (int)flx; y1 = (int)fly;
+    fx -= flx; fy -= fly;
+}
+
+static __device__ __forceinline__ void finish_M(const float r0[5], const GatherTaps& g, int H, int W, int x1, int y1,
+                                                float fx, float fy, float dx, float dy, float bxx, float by0, float by1,
+                                                float m[5])
+{
+    const bool inside = (unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1);
+    float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+    float s[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) s[c] = a00 * g.t0[c].a + a01 * g.t0[c].b + a10 * g.t1[c].a + a11 * g.t1[c].b;
+    float r2 = inside ? s[0] : 0.f;
+    float r3 = inside ? s[1] : 0.f;
+    float r4 = inside ? (r0[2] + s[2]) * 0.5f : r0[2];
+    float r5 = inside ? (r0[3] + s[3]) * 0.5f : r0[3];
+    float r6 = inside ? (r0[4] + s[4]) * 0.25f : r0[4] * 0.5f;
     r2 = (r0[0] - r2) * 0.5f;
     r3 = (r0[1] - r3) * 0.5f;
     r2 = r2 + (r4 * dy + r6 * dx);
     r3 = r3 + (r6 * dy + r5 * dx);
-    const int BORDER = 5;
-    if ((unsigned)(x - BORDER) >= (unsigned)(W - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(H - BORDER * 2)) {
-        // border[] = {0.14, 0.14, 0.4472, 0.4472, 0.4472}
-        float bx0 = x < BORDER ? (x < 2 ? 0.14f : 0.4472f) : 1.f;
-        float bx1 = x >= W - BORDER ? (W - x - 1 < 2 ? 0.14f : 0.4472f) : 1.f;
-        float by0 = y < BORDER ? (y < 2 ? 0.14f : 0.4472f) : 1.f;
-        float by1 = y >= H - BORDER ? (H - y - 1 < 2 ? 0.14f : 0.4472f) : 1.f;
-        float scale = bx0 * bx1 * by0 * by1;
-        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
-    }
+    float scale = bxx * by0 * by1; // ((bx0*bx1)*by0)*by1 as OpenCV; == 1.0f away from the border
+    r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
     m[0] = r4 * r4 + r6 * r6;
     m[1] = (r4 + r5) * r6;
     m[2] = r5 * r5 + r6 * r6;
     m[3] = r4 * r2 + r6 * r3;
     m[4] = r6 * r2 + r5 * r3;
+}
+
+static __device__ __forceinline__ void compute_M(const float r0[5], const float* __restrict__ R1, size_t HW,
+                                                 int H, int W, int x, int y, float dx, float dy, float m[5])
+{
+    int x1, y1; float fx, fy;
+    flow_target(x, y, dx, dy, x1, y1, fx, fy);
+    GatherTaps g;
+    gather_R1(R1, HW, H, W, x1, y1, g);
+    float by0 = y < 5 ? (y < 2 ? 0.14f : 0.4472f) : 1.f;
+    float by1 = y >= H - 5 ? (H - y - 1 < 2 ? 0.14f : 0.4472f) : 1.f;
+    finish_M(r0, g, H, W, x1, y1, fx, fy, dx, dy, border_factor(x, W), by0, by1, m);
 }
 
 static __device__ __forceinline__ float2 solve_flow(const double a[5], double scale)
