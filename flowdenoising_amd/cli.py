@@ -1,0 +1,190 @@
+"""Command line of flowdenoising.py, MI355X build.
+
+Same options as the reference (union of src/flowdenoising_sequential.py:446-473 and
+src/flowdenoising.py:384-415): -i/--input, -o/--output, -s/--sigma (Z Y X), -l/--levels,
+-w/--winsize, -v/--verbosity, -n/--no_OF, -m/--memory_map, -p/--number_of_processes,
+--recompute_flow, --show_fingerprint.  File-type dispatch and output dtypes follow seq:508-571.
+
+Defaults follow the parity oracle, flowdenoising_sequential.py: levels = 0, volume ends padded
+with the global mean, full Z->Y->X result.  `--compat par` switches to flowdenoising.py's own
+behaviour: levels = 3 by default, wrap-around volume ends (par:312), float32 TIFF output
+(par:548).  (par's loss of its X pass, par:290 + par:520, is not reproduced: the full Z->Y->X
+result is written, as src/flowdenoising_GPU.py:460 does.)
+
+New options: --device N (GPU index), --gpus N (shard over N GPUs of this node; re-launches itself
+under torch.distributed.run).
+"""
+import argparse
+import hashlib
+import logging
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+LOGGING_FORMAT = "[%(asctime)s] (%(levelname)s) %(message)s"  # seq:26
+SIGMA = 2.0
+OF_WINDOW_SIZE = 5
+
+
+def int_or_str(text):
+    """seq:433-438."""
+    try:
+        return int(text)
+    except ValueError:
+        return text
+
+
+def build_parser():
+    p = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter,
+                                description="3D Gaussian filtering controlled by the optical flow (MI355X build).")
+    p.add_argument("-i", "--input", type=int_or_str, help="Input a MRC-file or a multi-image TIFF-file",
+                   default="./volume.mrc")
+    p.add_argument("-o", "--output", type=int_or_str, help="Output a MRC-file or a multi-image TIFF-file",
+                   default="./denoised_volume.mrc")
+    p.add_argument("-s", "--sigma", nargs="+", help="Gaussian sigma for each dimension in the order (Z, Y, X)",
+                   default=(SIGMA, SIGMA, SIGMA))
+    p.add_argument("-l", "--levels", type=int_or_str, default=None,
+                   help="Number of levels of the Gaussian pyramid used by the optical flow estimator "
+                        "(default 0; 3 with --compat par)")
+    p.add_argument("-w", "--winsize", type=int_or_str, help="Size of the window used by the optical flow estimator",
+                   default=OF_WINDOW_SIZE)
+    p.add_argument("-v", "--verbosity", type=int_or_str, help="Verbosity level", default=0)
+    p.add_argument("-n", "--no_OF", action="store_true", help="Disable optical flow compensation")
+    p.add_argument("-m", "--memory_map", action="store_true", help="Enable memory-mapping (only for MRC files)")
+    p.add_argument("-p", "--number_of_processes", type=int_or_str, default=os.cpu_count(),
+                   help="Accepted for compatibility; slices are batched on the GPU instead of a process pool")
+    p.add_argument("--recompute_flow", action="store_true", help="Disable the use of adjacent optical flow fields")
+    p.add_argument("--show_fingerprint", action="store_true", help="Show a hash of this program")
+    p.add_argument("--compat", choices=("seq", "par"), default="seq",
+                   help="seq: flowdenoising_sequential.py semantics (mean-padded ends, levels 0); "
+                        "par: flowdenoising.py semantics (wrap-around ends, levels 3, float32 TIFF)")
+    p.add_argument("--device", type=int, default=0, help="GPU index")
+    p.add_argument("--gpus", type=int, default=1, help="Shard the volume over this many GPUs of the node")
+    return p
+
+
+def _feedback(state):
+    while True:
+        logging.info(f"{state['stage']}")
+        time.sleep(1)
+
+
+def _run_single(args, vol, kernels, l, w, device):
+    from . import _lib
+    from .operators import _params, handle
+    border = _lib.BORDER_WRAP if args.compat == "par" else _lib.BORDER_MEAN_PAD
+    params = _params(l, w, use_of=not args.no_OF, border_mode=border, chained=not args.recompute_flow)
+    vol32 = np.ascontiguousarray(vol, dtype=np.float32)
+    mean = vol32.mean()  # seq:420
+    return handle(device).filter_3d(vol32, kernels, mean, params)
+
+
+def _run_sharded(args, vol, kernels, l, w):
+    """Called under torch.distributed.run: every rank reads its Z-slab, rank 0 writes."""
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    from .distributed import SlabEngine, SlabPlan
+    from .operators import _params
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", device_id=dev)
+    plan = SlabPlan(vol.shape, world, rank)
+    slab = torch.from_numpy(np.ascontiguousarray(vol[plan.z0:plan.z0 + plan.zlen], dtype=np.float32)).to(dev)
+    h = _lib.Handle(local)
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    border = _lib.BORDER_WRAP if args.compat == "par" else _lib.BORDER_MEAN_PAD
+    params = _params(l, w, use_of=not args.no_OF, border_mode=border, chained=not args.recompute_flow)
+    out = SlabEngine(plan, h, dist).filter_3d(slab, kernels, params)
+    parts = [torch.empty((e - s,) + tuple(vol.shape[1:]), dtype=torch.float32, device=dev) for s, e in plan.parts[0]]
+    for r, g in enumerate(parts):   # slabs may differ in length: one broadcast per owner
+        if r == rank:
+            g.copy_(out)
+        dist.broadcast(g, src=r)
+    res = torch.cat(parts).cpu().numpy() if rank == 0 else None
+    dist.barrier()
+    dist.destroy_process_group()
+    return res
+
+
+def main(argv=None):
+    parser = build_parser()
+    args = parser.parse_args(argv)
+
+    if args.show_fingerprint:  # par:425-431 hashes the script; here: the library that does the work
+        from . import _lib
+        h = hashlib.sha256()
+        for fn in (os.path.abspath(__file__), _lib.LIB_PATH):
+            with open(fn, "rb") as f:
+                while chunk := f.read(1 << 16):
+                    h.update(chunk)
+        print("fingerprint =", h.hexdigest())
+
+    level = {2: logging.DEBUG, 1: logging.INFO}.get(args.verbosity, logging.CRITICAL)  # seq:480-487
+    logging.basicConfig(format=LOGGING_FORMAT, level=level)
+    if args.verbosity in (1, 2):
+        logging.info(f"Verbosity level = {args.verbosity}")
+
+    sharded = "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if args.gpus > 1 and not sharded:
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000),
+               os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flowdenoising.py")]
+        return subprocess.call(cmd + (sys.argv[1:] if argv is None else list(argv)))
+    rank = int(os.environ.get("RANK", "0")) if sharded else 0
+
+    sigma = [float(i) for i in args.sigma]
+    logging.info(f"sigma={tuple(sigma)}")
+    l = args.levels if args.levels is not None else (3 if args.compat == "par" else 0)
+    w = args.winsize
+
+    state = {"stage": "reading"}
+    t = threading.Thread(target=_feedback, args=(state,), daemon=True)  # seq:489-491
+    t.start()
+
+    from . import io as fio
+    from .operators import get_gaussian_kernel
+    logging.info(f"reading \"{args.input}\"")
+    t0 = time.perf_counter()
+    vol = fio.read_volume(args.input, mmap=args.memory_map)
+    logging.info(f"read \"{args.input}\" in {time.perf_counter() - t0} seconds")
+    logging.info(f"shape of the input volume (Z, Y, X) = {vol.shape}")
+    logging.info(f"type of the volume = {vol.dtype}")
+    if rank == 0:
+        logging.info(f"{args.input} max = {vol.max()}")
+        logging.info(f"{args.input} min = {vol.min()}")
+        logging.info(f"Input vol average = {vol.mean()}")
+
+    kernels = [get_gaussian_kernel(sigma[0]), get_gaussian_kernel(sigma[1]), get_gaussian_kernel(sigma[2])]  # seq:534-537
+    logging.info(f"length of each filter (Z, Y, X) = {[len(i) for i in kernels]}")
+
+    state["stage"] = "filtering"
+    t0 = time.perf_counter()
+    if sharded:
+        filtered = _run_sharded(args, vol, kernels, l, w)
+    else:
+        filtered = _run_single(args, vol, kernels, l, w, args.device)
+    logging.info(f"Volume filtered in {time.perf_counter() - t0} seconds")
+    if rank != 0:
+        return 0
+
+    logging.info(f"shape of the denoised volume (Z, Y, X) = {filtered.shape}")
+    logging.info(f"{args.output} type = {filtered.dtype}")
+    logging.info(f"{args.output} max = {filtered.max()}")
+    logging.info(f"{args.output} min = {filtered.min()}")
+    logging.info(f"Output vol average = {filtered.mean()}")
+    state["stage"] = "writing"
+    t0 = time.perf_counter()
+    fio.write_volume(args.output, filtered, tiff_float32=(args.compat == "par"))
+    logging.info(f"written \"{args.output}\" in {time.perf_counter() - t0} seconds")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,277 @@
+"""Volume I/O for the CLI: MRC2014 and multi-page TIFF, numpy only.
+
+Replaces the reference's calls into `mrcfile` and `skimage.io`/`tifffile`
+(src/flowdenoising_sequential.py:508-517 read, 558-571 write; src/flowdenoising.py:466-475,
+539-548), which are not installed in the target image.  Volumes are (Z, Y, X) arrays.
+
+MRC: 1024-byte header (nx, ny, nz, mode at words 1-4; nsymbt extended-header bytes at word 24;
+'MAP ' + machine stamp at bytes 208-215) followed by the raw array; modes 0/1/2/6/12 =
+int8/int16/float32/uint16/float16.  Output is always mode 2 with dmin/dmax/dmean/rms filled in,
+like mrcfile.new(...).set_data(float32) (seq:562-564).
+TIFF: uncompressed, single-sample pages of uint8/uint16/int16/uint32/float32/float64, classic or
+BigTIFF, either byte order; one IFD per page, or an ImageJ hyperstack with one IFD and
+contiguous data.
+"""
+import os
+import struct
+
+import numpy as np
+
+_MRC_MODES = {0: np.int8, 1: np.int16, 2: np.float32, 6: np.uint16, 12: np.float16}
+
+
+# ---------------------------------------------------------------------------- MRC
+def read_mrc(path, mmap=False):
+    with open(path, "rb") as f:
+        head = f.read(1024)
+    if len(head) < 1024:
+        raise ValueError(f"{path}: shorter than an MRC header")
+    stamp = head[212]
+    order = ">" if stamp == 0x11 else "<"
+    nx, ny, nz, mode = struct.unpack(order + "4i", head[:16])
+    if not (0 < nx < 1 << 20 and 0 < ny < 1 << 20 and 0 < nz < 1 << 20) or mode not in _MRC_MODES:
+        # some writers leave the stamp empty: try the other byte order before giving up
+        order = "<" if order == ">" else ">"
+        nx, ny, nz, mode = struct.unpack(order + "4i", head[:16])
+        if not (0 < nx < 1 << 20 and 0 < ny < 1 << 20 and 0 < nz < 1 << 20) or mode not in _MRC_MODES:
+            raise ValueError(f"{path}: not an MRC file this reader understands (nx,ny,nz,mode = {nx},{ny},{nz},{mode})")
+    nsymbt = struct.unpack(order + "i", head[92:96])[0]
+    dt = np.dtype(_MRC_MODES[mode]).newbyteorder(order)
+    offset = 1024 + max(nsymbt, 0)
+    count = nx * ny * nz
+    if os.path.getsize(path) < offset + count * dt.itemsize:
+        raise ValueError(f"{path}: truncated ({nz}x{ny}x{nx} mode {mode} needs {offset + count * dt.itemsize} bytes)")
+    if mmap:
+        return np.memmap(path, dtype=dt, mode="r", offset=offset, shape=(nz, ny, nx))
+    with open(path, "rb") as f:
+        f.seek(offset)
+        data = np.fromfile(f, dtype=dt, count=count)
+    return data.reshape(nz, ny, nx)
+
+
+def write_mrc(path, vol):
+    vol = np.ascontiguousarray(vol, dtype="<f4")
+    nz, ny, nx = vol.shape
+    h = bytearray(1024)
+    struct.pack_into("<10i", h, 0, nx, ny, nz, 2, 0, 0, 0, nx, ny, nz)
+    struct.pack_into("<6f", h, 40, float(nx), float(ny), float(nz), 90.0, 90.0, 90.0)   # cella (1 A voxels), cellb
+    struct.pack_into("<3i", h, 64, 1, 2, 3)                                             # mapc, mapr, maps
+    v64 = vol.astype(np.float64, copy=False) if vol.size < (1 << 27) else None
+    dmin, dmax = float(vol.min()), float(vol.max())
+    if v64 is not None:
+        dmean, rms = float(v64.mean()), float(v64.std())
+    else:  # slice-wise to bound memory
+        s = sum(float(z.sum(dtype=np.float64)) for z in vol)
+        dmean = s / vol.size
+        rms = float(np.sqrt(sum(float(((z.astype(np.float64) - dmean) ** 2).sum()) for z in vol) / vol.size))
+    struct.pack_into("<3f", h, 76, dmin, dmax, dmean)
+    struct.pack_into("<i", h, 88, 1)            # ispg: a volume
+    struct.pack_into("<i", h, 92, 0)            # nsymbt
+    struct.pack_into("<i", h, 108, 20140)       # nversion
+    h[208:212] = b"MAP "
+    h[212:216] = bytes([0x44, 0x44, 0, 0])      # little-endian machine stamp
+    struct.pack_into("<f", h, 216, rms)
+    label = b"flowdenoising_amd (MI355X)"
+    struct.pack_into("<i", h, 220, 1)
+    h[224:224 + len(label)] = label
+    with open(path, "wb") as f:
+        f.write(h)
+        vol.tofile(f)
+
+
+# ---------------------------------------------------------------------------- TIFF
+_TIFF_TYPES = {1: "B", 2: "c", 3: "H", 4: "I", 5: "II", 6: "b", 8: "h", 9: "i", 11: "f", 12: "d", 16: "Q", 17: "q", 18: "Q"}
+
+
+def _read_ifd(f, order, off, big):
+    f.seek(off)
+    n = struct.unpack(order + ("Q" if big else "H"), f.read(8 if big else 2))[0]
+    esz = 20 if big else 12
+    raw = f.read(n * esz)
+    nxt = struct.unpack(order + ("Q" if big else "I"), f.read(8 if big else 4))[0]
+    tags = {}
+    for i in range(n):
+        e = raw[i * esz:(i + 1) * esz]
+        tag, typ = struct.unpack(order + "HH", e[:4])
+        cnt = struct.unpack(order + ("Q" if big else "I"), e[4:12] if big else e[4:8])[0]
+        val = e[12:20] if big else e[8:12]
+        fmt = _TIFF_TYPES.get(typ)
+        if fmt is None:
+            continue
+        size = struct.calcsize("=" + fmt) * cnt
+        if size > len(val):
+            pos = struct.unpack(order + ("Q" if big else "I"), val)[0]
+            here = f.tell()
+            f.seek(pos)
+            data = f.read(size)
+            f.seek(here)
+        else:
+            data = val[:size]
+        if typ == 2:
+            tags[tag] = data.rstrip(b"\0").decode("latin-1")
+        else:
+            vals = struct.unpack(order + fmt * cnt, data)
+            tags[tag] = vals if typ != 5 else tuple(vals[i] / max(vals[i + 1], 1) for i in range(0, len(vals), 2))
+    return tags, nxt
+
+
+def _page_dtype(tags, order):
+    bps = tags.get(258, (1,))[0]
+    fmt = tags.get(339, (1,))[0]
+    kind = {1: "u", 2: "i", 3: "f"}.get(fmt)
+    if kind is None or bps not in (8, 16, 32, 64) or (kind == "f" and bps < 32):
+        raise ValueError(f"unsupported TIFF sample format (bits {bps}, format {fmt})")
+    return np.dtype(f"{order}{kind}{bps // 8}")
+
+
+def read_tiff(path):
+    with open(path, "rb") as f:
+        bo = f.read(2)
+        order = {b"II": "<", b"MM": ">"}.get(bo)
+        if order is None:
+            raise ValueError(f"{path}: not a TIFF file")
+        magic = struct.unpack(order + "H", f.read(2))[0]
+        if magic == 42:
+            big = False
+            off = struct.unpack(order + "I", f.read(4))[0]
+        elif magic == 43:
+            big = True
+            f.read(4)
+            off = struct.unpack(order + "Q", f.read(8))[0]
+        else:
+            raise ValueError(f"{path}: bad TIFF magic {magic}")
+        pages = []
+        first = None
+        while off:
+            tags, off = _read_ifd(f, order, off, big)
+            if first is None:
+                first = tags
+            if tags.get(259, (1,))[0] != 1:
+                raise ValueError(f"{path}: compressed TIFF (compression {tags[259][0]}) is not supported")
+            spp = tags.get(277, (1,))[0]
+            if spp != 1 and tags.get(284, (1,))[0] != 2:
+                raise ValueError(f"{path}: interleaved multi-sample (RGB) pages are not volumes")
+            W, H = tags[256][0], tags[257][0]
+            dt = _page_dtype(tags, order)
+            offs, cnts = tags[273], tags.get(279)
+            if spp != 1:   # planar samples (tifffile stores a 3- or 4-slice stack this way): one plane = one slice
+                if len(offs) != spp:
+                    raise ValueError(f"{path}: planar page with several strips per plane is not supported")
+                pages.extend((o, H, W, dt) for o in offs)
+            elif len(offs) == 1:
+                pages.append((offs[0], H, W, dt))
+            else:  # several strips: usable as one block when they are contiguous
+                if cnts is None or any(offs[i] + cnts[i] != offs[i + 1] for i in range(len(offs) - 1)):
+                    buf = bytearray()
+                    for o, c in zip(offs, cnts):
+                        f.seek(o)
+                        buf += f.read(c)
+                    pages.append((np.frombuffer(bytes(buf), dtype=dt).reshape(H, W), H, W, dt))
+                else:
+                    pages.append((offs[0], H, W, dt))
+        if not pages:
+            raise ValueError(f"{path}: no image pages")
+        _, H, W, dt = pages[0]
+        desc = first.get(270, "") if isinstance(first.get(270, ""), str) else ""
+        if len(pages) == 1 and desc.startswith("ImageJ=") and "images=" in desc:
+            n = int(desc.split("images=")[1].split()[0])   # ImageJ hyperstack: one IFD, contiguous pages
+            f.seek(pages[0][0])
+            return np.fromfile(f, dtype=dt, count=n * H * W).reshape(n, H, W)
+        out = np.empty((len(pages), H, W), dtype=dt.newbyteorder("="))
+        for i, (src, h, w, d) in enumerate(pages):
+            if (h, w, d) != (H, W, dt):
+                raise ValueError(f"{path}: pages differ in size or type")
+            if isinstance(src, np.ndarray):
+                out[i] = src
+            else:
+                f.seek(src)
+                out[i] = np.fromfile(f, dtype=dt, count=H * W).reshape(H, W)
+        return out
+
+
+def write_tiff(path, vol):
+    """One uncompressed strip and one IFD per page, little-endian; BigTIFF above 4 GiB."""
+    vol = np.ascontiguousarray(vol)
+    if vol.ndim == 2:
+        vol = vol[None]
+    kind = vol.dtype.kind
+    if kind not in "uif" or vol.dtype.itemsize not in (1, 2, 4, 8):
+        raise ValueError(f"cannot write dtype {vol.dtype} as TIFF")
+    vol = vol.astype(vol.dtype.newbyteorder("<"), copy=False)
+    Z, H, W = vol.shape
+    page_bytes = H * W * vol.dtype.itemsize
+    big = Z * (page_bytes + 512) + 1024 > (1 << 32) - (1 << 25)
+    fmt_code = {"u": 1, "i": 2, "f": 3}[kind]
+    desc = ('{"shape": [%d, %d, %d]}' % (Z, H, W)).encode() + b"\0"
+    with open(path, "wb") as f:
+        if big:
+            f.write(b"II" + struct.pack("<HHHQ", 43, 8, 0, 16))
+        else:
+            f.write(b"II" + struct.pack("<HI", 42, 8))
+        pos = f.tell()
+        for z in range(Z):
+            entries = [(256, 4, W), (257, 4, H), (258, 3, vol.dtype.itemsize * 8), (259, 3, 1), (262, 3, 1)]
+            if z == 0:
+                entries.append((270, 2, desc))
+            entries += [(273, 16 if big else 4, None), (277, 3, 1), (278, 4, H), (279, 16 if big else 4, page_bytes),
+                        (339, 3, fmt_code)]
+            n = len(entries)
+            ifd_size = (8 + n * 20 + 8) if big else (2 + n * 12 + 4)
+            extra = len(desc) if z == 0 and len(desc) > (8 if big else 4) else 0
+            data_off = pos + ifd_size + extra
+            data_off += (-data_off) % 16
+            next_ifd = data_off + page_bytes if z + 1 < Z else 0
+            next_ifd += (-next_ifd) % 2
+            buf = bytearray(struct.pack("<Q" if big else "<H", n))
+            for tag, typ, val in entries:
+                if tag == 273:
+                    val = data_off
+                if typ == 2:
+                    cnt = len(val)
+                    if cnt > (8 if big else 4):
+                        field = struct.pack("<Q" if big else "<I", pos + ifd_size)
+                    else:
+                        field = val.ljust(8 if big else 4, b"\0")
+                else:
+                    cnt = 1
+                    field = struct.pack("<" + {3: "H", 4: "I", 16: "Q"}[typ], val).ljust(8 if big else 4, b"\0")
+                buf += struct.pack("<HH", tag, typ) + struct.pack("<Q" if big else "<I", cnt) + field
+            buf += struct.pack("<Q" if big else "<I", next_ifd)
+            if extra:
+                buf += desc
+            f.seek(pos)
+            f.write(buf)
+            f.seek(data_off)
+            vol[z].tofile(f)
+            pos = next_ifd
+    return path
+
+
+# ---------------------------------------------------------------------------- dispatch (CLI rules)
+def is_mrc_input(path):
+    """par:466: 'mrc' in the last suffix, case-insensitive (seq:508 accepts only mrc/MRC)."""
+    return "mrc" in str(path).split(".")[-1].lower()
+
+
+def is_mrc_output(path):
+    """seq:558 / par:539: suffix exactly 'mrc' or 'MRC'."""
+    return str(path).split(".")[-1] in ("MRC", "mrc")
+
+
+def read_volume(path, mmap=False):
+    if is_mrc_input(path):
+        return read_mrc(path, mmap=mmap)
+    return read_tiff(path)
+
+
+def write_volume(path, vol, tiff_float32=False):
+    """seq:558-571: MRC float32, else TIFF uint8 if max < 256 else uint16 (values truncated by astype);
+    tiff_float32=True gives par:548's float32 TIFF."""
+    if is_mrc_output(path):
+        write_mrc(path, vol.astype(np.float32, copy=False))
+    elif tiff_float32:
+        write_tiff(path, vol.astype(np.float32, copy=False))
+    elif np.max(vol) < 256:
+        write_tiff(path, vol.astype(np.uint8))
+    else:
+        write_tiff(path, vol.astype(np.uint16))

@@ -1,0 +1,134 @@
+"""The N > 1 decomposition (flowdenoising_amd/distributed.py) on CPU: world_size 2 and 3 with the
+gloo backend, the pass compute injected from the oracle.  What is under test is the host logic:
+slab plan, halo exchange (mean-pad and wrap), the Z->Y->X->Z repartition, the global mean.
+The sharded result must equal the single-process oracle bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleBackend:
+    """Pass compute for the CPU tests (the product uses HipBackend)."""
+
+    def __init__(self, O):
+        self.O = O
+
+    def sweep_stack(self, stack, out, S, H, W, kernel, params):
+        r = kernel.size // 2
+        res = self.O.filter_axis_range(stack.numpy(), 0, kernel, params.levels, params.winsize, 0.0, r, r + S,
+                                       use_of=bool(params.use_of), chained=bool(params.chained))
+        out.copy_(__import__("torch").from_numpy(res[r:r + S]))
+
+    def local_sum(self, t):
+        return float(t.numpy().astype(np.float64).sum())
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, shape, sigmas, border_mode, use_of, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from flowdenoising_amd import _lib
+    from flowdenoising_amd.distributed import SlabEngine, SlabPlan
+    from flowdenoising_amd.synth import make_volume
+    from oracle import oracle as O
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        vol = make_volume(shape, seed=21, amplitude=100.0)
+        plan = SlabPlan(shape, world, rank)
+        slab = torch.from_numpy(vol[plan.z0:plan.z0 + plan.zlen].copy())
+        kernels = [None if s is None else O.get_gaussian_kernel(s) for s in sigmas]
+        params = _lib.SweepParams(0, 5, 3, 5, 1.2, border_mode, 1, int(use_of))
+        eng = SlabEngine(plan, OracleBackend(O), dist)
+        mean_auto = eng.global_mean(slab)
+        out = eng.filter_3d(slab, kernels, params, mean=vol.mean())
+        gathered = [torch.empty((e - s,) + tuple(shape[1:]), dtype=torch.float32) for s, e in plan.parts[0]]
+        dist.all_gather(gathered, out) if len({g.shape for g in gathered}) == 1 else _gather_uneven(dist, gathered, out, rank)
+        if rank == 0:
+            q.put((torch.cat(gathered).numpy(), float(mean_auto)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _gather_uneven(dist, gathered, out, rank):
+    for r, g in enumerate(gathered):
+        if r == rank:
+            g.copy_(out)
+        dist.broadcast(g, src=r)
+
+
+def _run(world, shape, sigmas, border_mode=0, use_of=True):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, sigmas, border_mode, use_of, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("world,shape", [(2, (12, 34, 36)), (3, (11, 34, 37))])
+def test_sharded_of_filter_equals_single_process(oracle, world, shape):
+    from flowdenoising_amd.synth import make_volume
+    sig = (1.0, 0.5, 1.0)
+    got, mean_auto = _run(world, shape, sig)
+    vol = make_volume(shape, seed=21, amplitude=100.0)
+    want = oracle.OF_filter(vol, [oracle.get_gaussian_kernel(s) for s in sig], 0, 5)
+    assert np.array_equal(got, want)
+    assert abs(mean_auto - float(vol.mean())) <= 2e-7 * abs(float(vol.mean()))
+
+
+def test_sharded_wrap_borders_and_axis_subset(oracle):
+    from flowdenoising_amd.synth import make_volume
+    shape, sig = (8, 34, 36), (1.0, None, 0.5)
+    got, _ = _run(2, shape, sig, border_mode=1)
+    vol = make_volume(shape, seed=21, amplitude=100.0)
+    ks = [None if s is None else oracle.get_gaussian_kernel(s) for s in sig]
+    want = oracle.OF_filter(vol, ks, 0, 5, border_mode=1)
+    assert np.array_equal(got, want)
+
+
+def test_sharded_no_of(oracle):
+    from flowdenoising_amd.synth import make_volume
+    shape, sig = (9, 20, 22), (1.5, 1.0, 1.0)   # halo (6) larger than a slab (4-5 slices)
+    got, _ = _run(2, shape, sig, use_of=False)
+    vol = make_volume(shape, seed=21, amplitude=100.0)
+    want = oracle.no_OF_filter(vol, [oracle.get_gaussian_kernel(s) for s in sig])
+    assert np.array_equal(got, want)
+
+
+def test_halo_runs_cover_every_halo_slice():
+    from flowdenoising_amd.distributed import SlabPlan
+    for world, n, r, wrap in [(2, 10, 3, False), (3, 7, 4, True), (4, 9, 2, True), (1, 5, 3, True)]:
+        plan = SlabPlan((n, n, n), world, 0)
+        runs = plan.halo_runs(0, r, wrap)
+        for d, (s, e) in enumerate(plan.parts[0]):
+            got = {}
+            for src, dst, s_loc, d_pos, cnt in runs:
+                if dst == d:
+                    for i in range(cnt):
+                        got[d_pos + i] = plan.parts[0][src][0] + s_loc + i
+            for p in list(range(r)) + list(range(r + e - s, 2 * r + e - s)):
+                g = s - r + p
+                if wrap:
+                    assert got[p] == g % n
+                elif 0 <= g < n:
+                    assert got[p] == g
+                else:
+                    assert p not in got

@@ -1,0 +1,150 @@
+"""GPU tests beyond the small parity cases: the CLI end to end, the slab engine on the HIP backend,
+and BASELINE.json's full-size images checked through (a) spot parity against the oracle on
+sub-volumes and (b) size-independent properties."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TIGHT_TOL = 2e-6
+
+
+def _vol(shape, seed=7):
+    from flowdenoising_amd.synth import make_volume
+    return make_volume(shape, seed=seed, amplitude=100.0)
+
+
+def test_cli_mrc_end_to_end_config0(fdn, oracle, tmp_path):
+    """BASELINE configs[0] in miniature: float32 MRC in, float32 MRC out, defaults of the oracle script."""
+    from flowdenoising_amd import io as fio
+    vol = _vol((10, 40, 44), seed=3)
+    fio.write_mrc(str(tmp_path / "in.mrc"), vol)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "flowdenoising.py"), "-i", str(tmp_path / "in.mrc"),
+                        "-o", str(tmp_path / "out.mrc"), "-s", "1.0", "0.5", "1.0", "-v", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = fio.read_mrc(str(tmp_path / "out.mrc"))
+    want = oracle.OF_filter(vol, [oracle.get_gaussian_kernel(s) for s in (1.0, 0.5, 1.0)], 0, 5)
+    assert got.dtype == np.float32 and rel_err(got, want) < TIGHT_TOL
+
+
+def test_cli_tiff_uint16_no_of_and_par_compat(fdn, oracle, tmp_path):
+    from flowdenoising_amd import io as fio
+    vol = (np.clip(_vol((6, 34, 36), seed=4), 0, None) * 4).astype(np.uint16)
+    fio.write_tiff(str(tmp_path / "in.tif"), vol)
+    exe = [sys.executable, os.path.join(ROOT, "flowdenoising.py"), "-i", str(tmp_path / "in.tif"), "-s", "0.5", "0.5", "0.5"]
+    r = subprocess.run(exe + ["-o", str(tmp_path / "a.tif"), "-n"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ks = [oracle.get_gaussian_kernel(0.5)] * 3
+    want = oracle.no_OF_filter(vol.astype(np.float32), ks)
+    got = fio.read_tiff(str(tmp_path / "a.tif"))
+    assert got.dtype == np.uint16 and np.array_equal(got, want.astype(np.uint16))     # seq:566-571
+    r = subprocess.run(exe + ["-o", str(tmp_path / "b.tif"), "--compat", "par", "-l", "0", "--recompute_flow"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = fio.read_tiff(str(tmp_path / "b.tif"))
+    want = oracle.OF_filter(vol.astype(np.float32), ks, 0, 5, border_mode=1, chained=False)
+    assert got.dtype == np.float32 and rel_err(got, want) < TIGHT_TOL                 # par:548, par:312
+
+
+def test_flowdenoising_class_mirrors_par(fdn, oracle):
+    vol = _vol((8, 34, 36), seed=6)
+    ks = [fdn.get_gaussian_kernel(0.5)] * 3
+    v = vol.copy()
+    fd = fdn.FlowDenoising(4, v, 0, 5, fdn.get_flow_with_prev_flow, fdn.warp_slice)
+    assert fd.filter(ks) is None                                                      # par:285-290 returns None
+    want = oracle.OF_filter(vol, ks, 0, 5, border_mode=1)
+    assert rel_err(fd.filtered_vol, want) < TIGHT_TOL and np.array_equal(fd.vol, fd.filtered_vol)
+
+
+def test_slab_engine_on_hip_backend_world1(fdn, oracle):
+    torch = pytest.importorskip("torch")
+    from flowdenoising_amd import _lib
+    from flowdenoising_amd.distributed import SlabEngine, SlabPlan
+    from flowdenoising_amd.operators import handle
+    vol = _vol((9, 36, 40), seed=8)
+    h = handle()
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        eng = SlabEngine(SlabPlan(vol.shape, 1, 0), h, None)
+        ks = [fdn.get_gaussian_kernel(s) for s in (1.0, 0.5, 0.5)]
+        params = _lib.SweepParams(0, 5, 3, 5, 1.2, 0, 1, 1)
+        out = eng.filter_3d(torch.from_numpy(vol).cuda(), ks, params).cpu().numpy()
+    finally:
+        h.set_stream(None)
+    want = oracle.OF_filter(vol, ks, 0, 5)
+    assert rel_err(out, want) < TIGHT_TOL
+
+
+def test_small_workspace_chunks_targets(fdn, oracle):
+    from flowdenoising_amd.operators import handle
+    vol = _vol((12, 34, 36), seed=9)
+    k = fdn.get_gaussian_kernel(1.0)
+    h = handle()
+    h.set_workspace_limit(3 * 34 * 36 * 16)   # room for 3 targets' flows per batch
+    try:
+        got = fdn.OF_filter_along_Z(vol, k, 0, 5, vol.mean())
+    finally:
+        h.set_workspace_limit(0)
+    assert rel_err(got, oracle.filter_along_axis(vol, 0, k, 0, 5, vol.mean())) < TIGHT_TOL
+
+
+def test_wide_window_uses_the_staged_path(fdn, oracle):
+    """winsize 15 (BASELINE configs[4]) goes through the general per-stage kernels."""
+    vol = _vol((6, 48, 52), seed=10)
+    k = fdn.get_gaussian_kernel(0.5)
+    got = fdn.OF_filter_along_Z(vol, k, 0, 15, vol.mean())
+    assert rel_err(got, oracle.filter_along_axis(vol, 0, k, 0, 15, vol.mean())) < TIGHT_TOL
+
+
+# ---- full-size images (BASELINE.json configs[1] and configs[2]) ---------------------------------
+@pytest.mark.parametrize("axis,shape", [(0, (40, 1024, 1024)), (1, (512, 40, 1024)), (2, (512, 1024, 40))])
+def test_full_size_images_spot_parity(fdn, oracle, axis, shape):
+    """sigma=2 (K=17) sweeps over full-size images (1024x1024 for Z; 512x1024 for Y and X): two target
+    slices are compared with the oracle run on the 17-slice sub-volume that feeds them."""
+    from flowdenoising_amd.synth import make_volume
+    vol = make_volume(shape, seed=1234 + 3, amplitude=100.0)
+    k = fdn.get_gaussian_kernel(2.0)
+    mean = vol.mean()
+    fn = [fdn.OF_filter_along_Z, fdn.OF_filter_along_Y, fdn.OF_filter_along_X][axis]
+    got = fn(vol, k, 0, 5, mean)
+    n = shape[axis]
+    for t in (3, n // 2):            # one target whose window reaches the mean padding, one interior
+        lo, hi = max(0, t - 8), min(n, t + 9)
+        sub = np.take(vol, range(lo, hi), axis=axis)
+        want = oracle.filter_axis_range(sub, axis, k, 0, 5, mean, t - lo, t - lo + 1, nthreads=1)
+        assert rel_err(np.take(got, [t], axis=axis), np.take(want, [t - lo], axis=axis)) < TIGHT_TOL
+
+
+def test_full_size_roll_equivariance_wrap(fdn):
+    """Size-independent property at configs[1] size (256x512x512, Z only): with wrap-around ends
+    (par:312) rolling the volume along Z rolls the result, bit for bit."""
+    from flowdenoising_amd import _lib
+    from flowdenoising_amd.synth import make_volume
+    vol = make_volume((256, 512, 512), seed=1234 + 2, amplitude=100.0)
+    k = fdn.get_gaussian_kernel(2.0)
+    a = fdn.OF_filter_along_Z(vol, k, 0, 5, 0.0, border_mode=_lib.BORDER_WRAP)
+    b = fdn.OF_filter_along_Z(np.roll(vol, 37, axis=0), k, 0, 5, 0.0, border_mode=_lib.BORDER_WRAP)
+    assert np.array_equal(np.roll(a, 37, axis=0), b)
+
+
+def test_full_size_identical_slices(fdn):
+    """Every slice equal (1024x1024 images): away from the padded ends and the image border the flow
+    is exactly zero, so the output is the f32 fold of v * w_i in the reference's tap order."""
+    rng = np.random.default_rng(0)
+    import scipy.ndimage
+    img = (scipy.ndimage.gaussian_filter(rng.standard_normal((1024, 1024)), 3) * 2000).astype(np.float32)
+    vol = np.broadcast_to(img, (24, 1024, 1024)).copy()
+    k = fdn.get_gaussian_kernel(2.0)
+    got = fdn.OF_filter_along_Z(vol, k, 0, 5, vol.mean())
+    acc = np.zeros_like(img)
+    order = list(range(7, -1, -1)) + [8] + list(range(9, 17))     # seq:95, 108, 110
+    for i in order:
+        acc = (acc.astype(np.float64) + img.astype(np.float64) * k[i]).astype(np.float32)
+    assert np.array_equal(got[12, :900, :900], acc[:900, :900])
