@@ -29,15 +29,39 @@ class SweepParams(ctypes.Structure):
 
 # every symbol include/flowdn.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "fdn_create", "fdn_destroy", "fdn_last_error", "fdn_set_stream", "fdn_synchronize",
+    "fdn_create", "fdn_destroy", "fdn_last_error", "fdn_set_stream", "fdn_reset_stream", "fdn_synchronize",
     "fdn_set_workspace_limit", "fdn_malloc", "fdn_free", "fdn_memcpy_h2d", "fdn_memcpy_d2h",
     "fdn_memset_f32", "fdn_gaussian_kernel", "fdn_farneback", "fdn_warp",
     "fdn_filter_axis_dev", "fdn_filter_axis", "fdn_filter_3d_dev", "fdn_filter_3d",
-    "fdn_mean_dev", "fdn_sum_dev", "fdn_sweep_stack_dev", "fdn_permute_dev",
+    "fdn_mean_host", "fdn_mean_dev", "fdn_sum_dev", "fdn_sweep_stack_dev", "fdn_permute_dev",
     "fdn_enable_timers", "fdn_get_timers", "fdn_version",
 ]
 
 _lib = None
+
+
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.  Two HIP runtimes in one process do not
+    both see the GPU, so if a torch installation exists (torch is optional: bench.py and the
+    multi-GPU engine use it for device memory and RCCL) its runtime is loaded first and
+    libflowdn.so binds to that one, whichever of the two modules the program imports first.
+    torch itself is NOT imported here."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load():
@@ -49,6 +73,7 @@ def load():
         raise FlowdnError(
             f"{LIB_PATH} not found: build it with `make -C flowdenoising_amd/csrc` "
             "(or __graft_entry__.build()); there is no CPU fallback")
+    _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(LIB_PATH)
     lib.fdn_last_error.restype = ctypes.c_char_p
     lib.fdn_version.restype = ctypes.c_char_p
@@ -80,6 +105,15 @@ def gaussian_kernel(sigma):
     return out[:K].copy()
 
 
+def mean_host(vol):
+    """fdn_mean_host: numpy's own float32 mean, restated in C (host only, needs no GPU)."""
+    lib = load()
+    vol = np.ascontiguousarray(vol, dtype=np.float32)
+    m = ctypes.c_float()
+    check(lib.fdn_mean_host(_ptr(vol), ctypes.c_size_t(vol.size), ctypes.byref(m)))
+    return np.float32(m.value)
+
+
 class Handle:
     """One fdn_handle: a GPU, its stream and the library-owned scratch."""
 
@@ -102,7 +136,11 @@ class Handle:
 
     # -- plumbing ------------------------------------------------------------------
     def set_stream(self, stream_ptr):
+        """Enqueue on this HIP stream (0/None = the legacy default stream torch uses by default)."""
         check(self._lib.fdn_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)))
+
+    def reset_stream(self):
+        check(self._lib.fdn_reset_stream(self._h))
 
     def synchronize(self):
         check(self._lib.fdn_synchronize(self._h))

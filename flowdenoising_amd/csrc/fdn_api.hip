@@ -35,10 +35,39 @@ static int fail(const char* fmt, ...)
     } while (0)
 
 // ---- host-side constants ----------------------------------------------------------
-// FarnebackPrepareGaussian (OpenCV optflowgf.cpp), reached from seq:62 with
-// poly_n = 5, poly_sigma = 1.2.  The 6x6 Gram matrix of (1,x,y,x^2,y^2,xy) under the
-// separable weight has only four distinct moments; its inverse entries are taken in
-// closed form from the (1,x^2,y^2) 3x3 block.
+// FarnebackPrepareGaussian (OpenCV optflowgf.cpp), reached from seq:62 with poly_n = 5,
+// poly_sigma = 1.2: f32 taps g, x*g, x^2*g and four entries of the inverse of the 6x6 Gram matrix
+// of (1, x, y, x^2, y^2, xy).  The inverse follows cv::invert(DECOMP_CHOLESKY) operation by
+// operation: the last bit of ig03/ig33 decides the f32 rounding of a handful of expansion
+// coefficients per volume, and the chained flow solve amplifies even that.
+static void spd6_inverse_cholesky(double G[6][6], double X[6][6])
+{
+    for (int r = 0; r < 6; r++)
+        for (int c = 0; c < 6; c++) X[r][c] = r == c ? 1.0 : 0.0;
+    for (int r = 0; r < 6; r++) {                       // G <- L, with 1/L_rr on the diagonal
+        for (int c = 0; c < r; c++) {
+            double acc = G[r][c];
+            for (int q = 0; q < c; q++) acc -= G[r][q] * G[c][q];
+            G[r][c] = acc * G[c][c];
+        }
+        double acc = G[r][r];
+        for (int q = 0; q < r; q++) { double t = G[r][q]; acc -= t * t; }
+        G[r][r] = 1. / sqrt(acc);
+    }
+    for (int r = 0; r < 6; r++)                         // L Y = I
+        for (int c = 0; c < 6; c++) {
+            double acc = X[r][c];
+            for (int q = 0; q < r; q++) acc -= G[r][q] * X[q][c];
+            X[r][c] = acc * G[r][r];
+        }
+    for (int r = 5; r >= 0; r--)                        // L^T X = Y
+        for (int c = 0; c < 6; c++) {
+            double acc = X[r][c];
+            for (int q = 5; q > r; q--) acc -= G[q][r] * X[q][c];
+            X[r][c] = acc * G[r][r];
+        }
+}
+
 void prepare_poly_consts(int n, double sigma, PolyConsts* pc)
 {
     if (sigma < 1.1920928955078125e-07) sigma = n * 0.3;
@@ -55,20 +84,24 @@ void prepare_poly_consts(int n, double sigma, PolyConsts* pc)
         xg[x] = (float)(x * g[x]);
         xxg[x] = (float)(x * x * g[x]);
     }
-    double a = 0, b = 0, c = 0, d = 0; // G(0,0), G(1,1), G(3,3), G(5,5)
+    double G[6][6] = {};
     for (int y = -n; y <= n; y++)
         for (int x = -n; x <= n; x++) {
-            a += g[y] * g[x];
-            b += g[y] * g[x] * x * x;
-            c += g[y] * g[x] * x * x * x * x;
-            d += g[y] * g[x] * x * x * y * y;
+            G[0][0] += g[y] * g[x];
+            G[1][1] += g[y] * g[x] * x * x;
+            G[3][3] += g[y] * g[x] * x * x * x * x;
+            G[5][5] += g[y] * g[x] * x * x * y * y;
         }
-    double q = a * (c + d) - 2 * b * b;
+    G[2][2] = G[0][3] = G[0][4] = G[3][0] = G[4][0] = G[1][1];
+    G[4][4] = G[3][3];
+    G[3][4] = G[4][3] = G[5][5];
+    double X[6][6];
+    spd6_inverse_cholesky(G, X);
     pc->n = n;
-    pc->ig11 = 1. / b;
-    pc->ig55 = 1. / d;
-    pc->ig03 = -b / q;
-    pc->ig33 = (a * c - b * b) / ((c - d) * q);
+    pc->ig11 = X[1][1];
+    pc->ig03 = X[0][3];
+    pc->ig33 = X[3][3];
+    pc->ig55 = X[5][5];
     for (int k = 0; k <= n; k++) { pc->g[k] = g[k]; pc->xg[k] = xg[k]; pc->xxg[k] = xxg[k]; }
 }
 
@@ -442,7 +475,14 @@ FDN_API int fdn_set_stream(fdn_handle h, void* s)
 {
     FDN_ENTER(h);
     FDN_HIP(hipStreamSynchronize(h->stream));
-    h->stream = s ? (hipStream_t)s : h->own_stream;
+    h->stream = (hipStream_t)s; // NULL is a valid choice: the legacy default stream (what torch uses by default)
+    return 0;
+}
+FDN_API int fdn_reset_stream(fdn_handle h)
+{
+    FDN_ENTER(h);
+    FDN_HIP(hipStreamSynchronize(h->stream));
+    h->stream = h->own_stream;
     return 0;
 }
 FDN_API int fdn_synchronize(fdn_handle h)
@@ -667,6 +707,43 @@ FDN_API int fdn_mean_dev(fdn_handle h, const float* d_in, size_t count, float* m
     double s = 0;
     if (fdn_sum_dev(h, d_in, count, &s)) return -1;
     *mean_out = (float)(s / (double)count);
+    return 0;
+}
+
+// numpy's float32 add.reduce over a contiguous array (loops.c.src @TYPE@_pairwise_sum): blocks of
+// <= 128 elements are summed with 8 interleaved accumulators, larger ranges split at
+// n/2 rounded down to a multiple of 8.  vol.mean() (seq:420) = f32(sum) / f32(n).
+static float np_pairwise_sum_f32(const float* a, size_t n)
+{
+    if (n < 8) {
+        float res = 0.f;
+        for (size_t i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        float r[8];
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        size_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    size_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum_f32(a, n2) + np_pairwise_sum_f32(a + n2, n - n2);
+}
+
+FDN_API int fdn_mean_host(const float* in, size_t count, float* mean_out)
+{
+    if (!in || !mean_out) return fail("NULL pointer");
+    if (!count) return fail("empty volume");
+    // the reduction runs through numpy's buffered iterator: pairwise sums of 8192-element chunks,
+    // accumulated left to right in float32
+    float tot = 0.f;
+    for (size_t s = 0; s < count; s += 8192) tot += np_pairwise_sum_f32(in + s, std::min<size_t>(8192, count - s));
+    *mean_out = tot / (float)count;
     return 0;
 }
 

@@ -34,6 +34,9 @@ static __device__ __forceinline__ float border_factor(int i, int n)
     return b0 * b1;
 }
 
+// OpenCV's "(unsigned)(i - BORDER) >= (unsigned)(n - BORDER*2)"
+static __device__ __forceinline__ bool border_test(int i, int n) { return (unsigned)(i - 5) >= (unsigned)(n - 10); }
+
 struct GatherTaps { float2u t0[5], t1[5]; };
 
 // issue the ten 8-byte loads of the bilinear gather (two adjacent taps per row per plane)
@@ -58,7 +61,7 @@ static __device__ __forceinline__ void flow_target(int x, int y, float dx, float
 
 static __device__ __forceinline__ void finish_M(const float r0[5], const GatherTaps& g, int H, int W, int x1, int y1,
                                                 float fx, float fy, float dx, float dy, float bxx, float by0, float by1,
-                                                float m[5])
+                                                bool damp, float m[5])
 {
     const bool inside = (unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1);
     float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
@@ -74,7 +77,10 @@ static __device__ __forceinline__ void finish_M(const float r0[5], const GatherT
     r3 = (r0[1] - r3) * 0.5f;
     r2 = r2 + (r4 * dy + r6 * dx);
     r3 = r3 + (r6 * dy + r5 * dx);
-    float scale = bxx * by0 * by1; // ((bx0*bx1)*by0)*by1 as OpenCV; == 1.0f away from the border
+    // ((bx0*bx1)*by0)*by1 as OpenCV, == 1.0f away from the border.  `damp` is OpenCV's own region test
+    // ((unsigned)(x-5) >= (unsigned)(W-10) || same for y): for images under 10 pixels it is NOT
+    // "within 5 pixels of an edge" (the unsigned difference wraps), and the factors are skipped.
+    float scale = damp ? bxx * by0 * by1 : 1.f;
     r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
     m[0] = r4 * r4 + r6 * r6;
     m[1] = (r4 + r5) * r6;
@@ -92,7 +98,7 @@ static __device__ __forceinline__ void compute_M(const float r0[5], const float*
     gather_R1(R1, HW, H, W, x1, y1, g);
     float by0 = y < 5 ? (y < 2 ? 0.14f : 0.4472f) : 1.f;
     float by1 = y >= H - 5 ? (H - y - 1 < 2 ? 0.14f : 0.4472f) : 1.f;
-    finish_M(r0, g, H, W, x1, y1, fx, fy, dx, dy, border_factor(x, W), by0, by1, m);
+    finish_M(r0, g, H, W, x1, y1, fx, fy, dx, dy, border_factor(x, W), by0, by1, border_test(x, W) || border_test(y, H), m);
 }
 
 static __device__ __forceinline__ float2 solve_flow(const double a[5], double scale)

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256, 2) void k_farneback_fused(const float* __restr
     float* acc = acc_base + (size_t)b * HW;
     float (*ring)[RS][5][64] = ringL[wv];
     const float bxx = border_factor(xc, W);
+    const bool xdamp = border_test(xc, W);
 
     // Lanes the horizontal window of this lane reads: the lane that owns column clamp(x+j).
     // (Replica lanes outside the image are never read: a replica's own window is shifted, so
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void k_farneback_fused(const float* __restr
             // ---- matrices ------------------------------------------------------------------
             float by0, by1, mm[5];
             row_factor(t, by0, by1);
-            finish_M(r0A, gA, H, W, x1A, y1A, fxA, fyA, fA.x, fA.y, bxx, by0, by1, mm);
+            finish_M(r0A, gA, H, W, x1A, y1A, fxA, fyA, fA.x, fA.y, bxx, by0, by1, xdamp || border_test(t, H), mm);
 #pragma unroll
             for (int j = RS - 1; j >= 1; j--)
 #pragma unroll
@@ -247,7 +248,8 @@ __global__ __launch_bounds__(256, 2) void k_farneback_fused(const float* __restr
 #pragma unroll
             for (int k = 1; k < ITERS; k++) {
                 row_factor(t - k * (MH + 1), by0, by1);
-                finish_M(r0k[k], gk[k], H, W, x1k[k], y1k[k], fxk[k], fyk[k], f[k].x, f[k].y, bxx, by0, by1, mm);
+                finish_M(r0k[k], gk[k], H, W, x1k[k], y1k[k], fxk[k], fyk[k], f[k].x, f[k].y, bxx, by0, by1,
+                         xdamp || border_test(t - k * (MH + 1), H), mm);
 #pragma unroll
                 for (int c = 0; c < 5; c++) ring[k - 1][slot[k]][c][lane] = mm[c];
             }

@@ -59,9 +59,11 @@ typedef struct fdn_sweep_params {
 int fdn_create(int device, fdn_handle* out);
 int fdn_destroy(fdn_handle h);
 const char* fdn_last_error(void);
-/* Use an external HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL restores
- * the handle's own stream. */
+/* Enqueue on an external HIP stream instead (e.g. torch.cuda.current_stream().cuda_stream, so that
+ * library kernels and torch/RCCL ops order on one stream).  NULL means the legacy default stream.
+ * fdn_reset_stream goes back to the handle's own (non-blocking) stream. */
 int fdn_set_stream(fdn_handle h, void* hip_stream);
+int fdn_reset_stream(fdn_handle h);
 int fdn_synchronize(fdn_handle h);
 /* Cap on library-owned scratch (polynomial expansions, flows); 0 = default (device free
  * memory minus a reserve).  Sweeps are chunked over target slices to respect it. */
@@ -115,7 +117,12 @@ int fdn_filter_3d(fdn_handle h, const float* in, float* out, int Z, int Y, int X
                   const double* const kernels[3], const int K[3], float pad_value,
                   const fdn_sweep_params* p);
 
-/* vol.mean() of seq:420 on a device volume (float64 accumulation, returned as float32) */
+/* vol.mean() of seq:420 for a contiguous float32 HOST volume, bit-identical to numpy's (float32
+ * pairwise summation).  The padded borders make the result sensitive to the last bit of this
+ * value, so use it (or numpy itself) whenever bit-faithfulness to the reference matters. */
+int fdn_mean_host(const float* in, size_t count, float* mean_out);
+/* the same mean of a DEVICE volume, accumulated in float64 and rounded once: at most 1 ulp from
+ * numpy's value (used when the volume only exists on the GPU, e.g. across ranks) */
 int fdn_mean_dev(fdn_handle h, const float* d_in, size_t count, float* mean_out);
 /* sum only (float64), for the multi-GPU all-reduce of the mean */
 int fdn_sum_dev(fdn_handle h, const float* d_in, size_t count, double* sum_out);

@@ -316,25 +316,40 @@ typedef struct {
     double ig11, ig03, ig33, ig55;
 } polyexp_consts_t;
 
-/* in-place Gauss-Jordan inverse of a 6x6 SPD matrix (cv: G.inv(DECOMP_CHOLESKY)) */
-static void inv6(double A[6][6])
+/* inverse of a 6x6 SPD matrix the way cv::invert(DECOMP_CHOLESKY) does it for n > 3 (OpenCV
+ * hal CholImpl): L L^T factorisation with 1/sqrt on the diagonal, then forward and backward
+ * substitution on the identity. */
+static int chol_inv6(double A[6][6], double inv[6][6])
 {
-    double B[6][12];
-    for (int i = 0; i < 6; i++)
-        for (int j = 0; j < 12; j++)
-            B[i][j] = j < 6 ? A[i][j] : (j - 6 == i ? 1.0 : 0.0);
-    for (int c = 0; c < 6; c++) {
-        int p = c;
-        for (int r = c + 1; r < 6; r++) if (fabs(B[r][c]) > fabs(B[p][c])) p = r;
-        if (p != c) for (int j = 0; j < 12; j++) { double t = B[c][j]; B[c][j] = B[p][j]; B[p][j] = t; }
-        double d = B[c][c];
-        for (int j = 0; j < 12; j++) B[c][j] /= d;
-        for (int r = 0; r < 6; r++) if (r != c) {
-            double f = B[r][c];
-            if (f != 0.0) for (int j = 0; j < 12; j++) B[r][j] -= f * B[c][j];
+    const int m = 6;
+    double s;
+    int i, j, k;
+    for (i = 0; i < m; i++)
+        for (j = 0; j < m; j++) inv[i][j] = i == j ? 1.0 : 0.0;
+    for (i = 0; i < m; i++) {
+        for (j = 0; j < i; j++) {
+            s = A[i][j];
+            for (k = 0; k < j; k++) s -= A[i][k] * A[j][k];
+            A[i][j] = s * A[j][j];
         }
+        s = A[i][i];
+        for (k = 0; k < j; k++) { double t = A[i][k]; s -= t * t; }
+        if (s < 2.220446049250313e-16) return 0;
+        A[i][i] = 1. / sqrt(s);
     }
-    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) A[i][j] = B[i][j + 6];
+    for (i = 0; i < m; i++)
+        for (j = 0; j < m; j++) {
+            s = inv[i][j];
+            for (k = 0; k < i; k++) s -= A[i][k] * inv[k][j];
+            inv[i][j] = s * A[i][i];
+        }
+    for (i = m - 1; i >= 0; i--)
+        for (j = 0; j < m; j++) {
+            s = inv[i][j];
+            for (k = m - 1; k > i; k--) s -= A[k][i] * inv[k][j];
+            inv[i][j] = s * A[i][i];
+        }
+    return 1;
 }
 
 /* FarnebackPrepareGaussian */
@@ -366,11 +381,12 @@ static void prepare_gaussian(int n, double sigma, polyexp_consts_t* pc)
     G[2][2] = G[0][3] = G[0][4] = G[3][0] = G[4][0] = G[1][1];
     G[4][4] = G[3][3];
     G[3][4] = G[4][3] = G[5][5];
-    inv6(G);
-    pc->ig11 = G[1][1];
-    pc->ig03 = G[0][3];
-    pc->ig33 = G[3][3];
-    pc->ig55 = G[5][5];
+    double invG[6][6];
+    chol_inv6(G, invG);
+    pc->ig11 = invG[1][1];
+    pc->ig03 = invG[0][3];
+    pc->ig33 = invG[3][3];
+    pc->ig55 = invG[5][5];
 }
 
 /* FarnebackPolyExp: src HxW f32 -> dst HxWx5 f32 (interleaved).
@@ -526,6 +542,38 @@ static void update_flow_blur(const float* R0, const float* R1, float* flow, floa
             }
         }
         free(V);
+        if (update) update_matrices(R0, R1, flow, M, H, W, 0, H);
+        return;
+    }
+    if (box_mode == 2) {
+        /* OpenCV's vertical running sum (the f32-fed recurrence, exactly as below) but the
+         * horizontal window summed directly in f64 instead of OpenCV's f64 running sum.  This is
+         * the order the HIP kernels use: a running sum along x is a serial chain across the whole
+         * row, which a band-parallel kernel cannot reproduce.  The two differ only by f64
+         * rounding (~1e-16 relative), which the near-singular 2x2 solve can still amplify. */
+        double* vs = (double*)malloc((size_t)W * 5 * sizeof(double));
+        const float* r0 = M;
+        for (int x = 0; x < W * 5; x++) vs[x] = r0[x] * (m + 2);
+        for (int y = 1; y < m; y++) {
+            const float* srow = M + (size_t)(y < H - 1 ? y : H - 1) * W * 5;
+            for (int x = 0; x < W * 5; x++) vs[x] += srow[x];
+        }
+        for (int y = 0; y < H; y++) {
+            float* fl = flow + (size_t)y * W * 2;
+            const float* s0 = M + (size_t)(y - m - 1 > 0 ? y - m - 1 : 0) * W * 5;
+            const float* s1 = M + (size_t)(y + m < H - 1 ? y + m : H - 1) * W * 5;
+            for (int x = 0; x < W * 5; x++) vs[x] += s1[x] - s0[x];
+            for (int x = 0; x < W; x++) {
+                double a[5];
+                for (int c = 0; c < 5; c++) {
+                    double s = 0;
+                    for (int j = -m; j <= m; j++) s += vs[clampi(x + j, 0, W - 1) * 5 + c];
+                    a[c] = s;
+                }
+                solve_flow(a[0], a[1], a[2], a[3], a[4], scale, fl + x * 2);
+            }
+        }
+        free(vs);
         if (update) update_matrices(R0, R1, flow, M, H, W, 0, H);
         return;
     }

@@ -20,7 +20,8 @@ INTER_LINEAR = 1
 INTER_AREA = 3
 
 BOX_RUNNING = 0   # OpenCV's running sums (faithful restatement)
-BOX_DIRECT = 1    # direct f64 window sums (what the HIP kernels compute)
+BOX_DIRECT = 1    # direct f64 window sums in both directions (for sensitivity studies)
+BOX_VRUN_HDIRECT = 2  # OpenCV's vertical running sum + direct f64 horizontal window: the kernels' order
 
 
 def build(force=False):

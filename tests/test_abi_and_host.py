@@ -38,6 +38,15 @@ def test_host_only_entry_points(fdn):
     assert lib.fdn_synchronize(None) < 0 and b"NULL" in lib.fdn_last_error()
 
 
+def test_mean_host_is_numpys_float32_mean(fdn):
+    rng = np.random.default_rng(0)
+    for n in (1, 5, 8, 100, 128, 129, 1000, 4099, 65537, 1 << 20, (1 << 21) + 77):
+        a = (rng.standard_normal(n) * 100 + 1000).astype(np.float32)
+        assert fdn._lib.mean_host(a) == a.mean(), n
+    v = (rng.standard_normal((13, 57, 91)) * 50 + 300).astype(np.float32)
+    assert fdn._lib.mean_host(v) == v.mean()
+
+
 def test_no_cpu_fallback_when_library_is_missing(tmp_path, monkeypatch):
     import flowdenoising_amd._lib as L
     monkeypatch.setattr(L, "_lib", None)

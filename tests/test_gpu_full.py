@@ -75,9 +75,11 @@ def test_slab_engine_on_hip_backend_world1(fdn, oracle):
         eng = SlabEngine(SlabPlan(vol.shape, 1, 0), h, None)
         ks = [fdn.get_gaussian_kernel(s) for s in (1.0, 0.5, 0.5)]
         params = _lib.SweepParams(0, 5, 3, 5, 1.2, 0, 1, 1)
-        out = eng.filter_3d(torch.from_numpy(vol).cuda(), ks, params).cpu().numpy()
+        t = torch.from_numpy(vol).cuda()
+        assert abs(float(eng.global_mean(t)) - float(vol.mean())) <= 1.2e-7 * abs(float(vol.mean()))
+        out = eng.filter_3d(t, ks, params, mean=vol.mean()).cpu().numpy()   # seq:420's own value
     finally:
-        h.set_stream(None)
+        h.reset_stream()
     want = oracle.OF_filter(vol, ks, 0, 5)
     assert rel_err(out, want) < TIGHT_TOL
 
