@@ -152,6 +152,9 @@ struct fdn_ctx {
     hipStream_t stream = nullptr;
     size_t ws_limit = 0;
     DevBuf R, M0, M1, flow, stack, sweep_out, vol_a, vol_b, partials, pair;
+    DevBuf Rpyr, flow_pyr, pyr_tmp, area_tab;   // pyramid levels >= 1
+    struct AreaKey { int sh, sw, dh, dw; } area_key = {0, 0, 0, 0};
+    struct AreaPtrs { const int *x_si, *x_start, *y_si, *y_start; const float *x_alpha, *y_alpha; } area = {};
     // timers: event pairs are recorded asynchronously and resolved in fdn_get_timers
     bool timers = false;
     double tms[FDN_TIMER_COUNT] = {};
@@ -239,6 +242,110 @@ static int effective_levels(int levels, int H, int W)
     return k;
 }
 
+// ---- pyramid (levels > 0): FarnebackOpticalFlowImpl::calc's per-level geometry ----------
+struct PyrLevel { int h, w, smooth_sz; double sigma, scale; size_t r_off; size_t f_off; };
+
+static std::vector<PyrLevel> pyramid_levels(int levels, int H, int W)
+{
+    int L = effective_levels(levels, H, W);
+    std::vector<PyrLevel> v(L + 1);
+    for (int k = 0; k <= L; k++) {
+        double scale = 1;
+        for (int i = 0; i < k; i++) scale *= 0.5;
+        double sigma = (1. / scale - 1) * 0.5;
+        int smooth = (int)lrint(sigma * 5) | 1;
+        v[k] = PyrLevel{(int)lrint(H * scale), (int)lrint(W * scale), smooth < 3 ? 3 : smooth, sigma, scale, 0, 0};
+    }
+    return v;
+}
+
+// cv::computeResizeAreaTab in CSR form (entries of output index d are [start[d], start[d+1]))
+static void area_table(int ssize, int dsize, std::vector<int>& si, std::vector<float>& alpha, std::vector<int>& start)
+{
+    double scale = (double)ssize / dsize;
+    si.clear(); alpha.clear(); start.assign(1, 0);
+    for (int d = 0; d < dsize; d++) {
+        double f1 = d * scale, f2 = f1 + scale;
+        double cell = std::min(scale, ssize - f1);
+        int s1 = (int)ceil(f1), s2 = (int)floor(f2);
+        s2 = std::min(s2, ssize - 1);
+        s1 = std::min(s1, s2);
+        if (s1 - f1 > 1e-3) { si.push_back(s1 - 1); alpha.push_back((float)((s1 - f1) / cell)); }
+        for (int q = s1; q < s2; q++) { si.push_back(q); alpha.push_back((float)(1.0 / cell)); }
+        if (f2 - s2 > 1e-3) { si.push_back(s2); alpha.push_back((float)(std::min(std::min(f2 - s2, 1.), cell) / cell)); }
+        start.push_back((int)si.size());
+    }
+}
+
+static int ensure_area_tables(fdn_ctx* h, int sh, int sw, int dh, int dw)
+{
+    if (h->area_key.sh == sh && h->area_key.sw == sw && h->area_key.dh == dh && h->area_key.dw == dw) return 0;
+    std::vector<int> xsi, xst, ysi, yst;
+    std::vector<float> xa, ya;
+    area_table(sw, dw, xsi, xa, xst);
+    area_table(sh, dh, ysi, ya, yst);
+    size_t n = xsi.size() + xa.size() + xst.size() + ysi.size() + ya.size() + yst.size();
+    if (ensure(h, h->area_tab, n * 4)) return -1;
+    FDN_HIP(hipStreamSynchronize(h->stream));
+    char* d = (char*)h->area_tab.p;
+    auto put = [&](const void* src, size_t cnt) -> const void* {
+        const void* at = d;
+        (void)hipMemcpy(d, src, cnt * 4, hipMemcpyHostToDevice);
+        d += cnt * 4;
+        return at;
+    };
+    h->area.x_si = (const int*)put(xsi.data(), xsi.size());
+    h->area.x_alpha = (const float*)put(xa.data(), xa.size());
+    h->area.x_start = (const int*)put(xst.data(), xst.size());
+    h->area.y_si = (const int*)put(ysi.data(), ysi.size());
+    h->area.y_alpha = (const float*)put(ya.data(), ya.size());
+    h->area.y_start = (const int*)put(yst.data(), yst.size());
+    h->area_key = {sh, sw, dh, dw};
+    return 0;
+}
+
+// cv::resize as calc() uses it, on nimg device images of cn interleaved channels
+static int resize_dev(fdn_ctx* h, const float* in, int sh, int sw, float* out, int dh, int dw, int cn, int nimg,
+                      int interp, bool apply_ps, double ps)
+{
+    if (resize_needs_tables(sh, sw, dh, dw, interp)) {
+        if (ensure_area_tables(h, sh, sw, dh, dw)) return -1;
+        resize_area_tab(in, sh, sw, out, dh, dw, cn, nimg, h->area.x_si, h->area.x_alpha, h->area.x_start,
+                        h->area.y_si, h->area.y_alpha, h->area.y_start, apply_ps, ps, h->stream);
+    } else {
+        resize_images(in, sh, sw, out, dh, dw, cn, nimg, interp, apply_ps, ps, h->stream);
+    }
+    return 0;
+}
+
+// R_k[s] = polyexp(resize(GaussianBlur(img[s], smooth_k, sigma_k), (w_k, h_k), INTER_LINEAR)) for levels
+// k >= 1 of every image; lv[k].r_off (floats) locates level k inside h->Rpyr.
+static int build_R_pyramid(fdn_ctx* h, const float* imgs, int nimg, int H, int W, std::vector<PyrLevel>& lv, const PolyConsts& pc)
+{
+    const size_t HW = (size_t)H * W;
+    size_t total = 0;
+    for (size_t k = 1; k < lv.size(); k++) { lv[k].r_off = total; total += (size_t)nimg * 5 * lv[k].h * lv[k].w; }
+    if (ensure(h, h->Rpyr, total * sizeof(float))) return -1;
+    const int chunk = std::max(1, std::min(nimg, (int)((size_t)(1u << 30) / (HW * 12))));
+    if (ensure(h, h->pyr_tmp, (size_t)chunk * HW * 3 * sizeof(float))) return -1;
+    float* tmp = (float*)h->pyr_tmp.p;
+    float* blurred = tmp + (size_t)chunk * HW;
+    float* small = blurred + (size_t)chunk * HW;
+    ScopedTimer t(h, FDN_TIMER_POLYEXP);
+    for (size_t k = 1; k < lv.size(); k++) {
+        if (lv[k].smooth_sz > FDN_MAX_BLUR_TAPS) return fail("pyramid level %zu needs a %d-tap blur (max %d)", k, lv[k].smooth_sz, FDN_MAX_BLUR_TAPS);
+        BlurTaps bt;
+        prepare_blur_taps(lv[k].smooth_sz, lv[k].sigma, &bt);
+        for (int s0 = 0; s0 < nimg; s0 += chunk) {
+            int n = std::min(chunk, nimg - s0);
+            launch_gaussian_blur(imgs + (size_t)s0 * HW, tmp, blurred, n, H, W, bt, h->stream);
+            if (resize_dev(h, blurred, H, W, small, lv[k].h, lv[k].w, 1, n, 1, false, 1.0)) return -1;
+            launch_polyexp(small, (float*)h->Rpyr.p + lv[k].r_off + (size_t)s0 * 5 * lv[k].h * lv[k].w, n, lv[k].h, lv[k].w, pc, h->stream);
+        }
+    }
+    return 0;
+}
+
 // Farneback level-0 iterations for a batch of pairs whose R planes are in Rstack and whose
 // flows (initial -> final) are in `flow`; M0/M1 are ping-pong scratch for npairs.
 static void run_iterations(fdn_ctx* h, const float* Rstack, float* flow, float* M0, float* M1, PairBatch pb,
@@ -255,6 +362,38 @@ static void run_iterations(fdn_ctx* h, const float* Rstack, float* flow, float* 
         launch_update_flow(Rstack, cur, update ? nxt : nullptr, flow, pb, H, W, winsize, h->stream);
         std::swap(cur, nxt);
     }
+}
+
+// All levels of calc() for a batch of pairs: coarsest flow = INTER_AREA shrink of the initial flow
+// times the level scale (zeros without one), iterate, INTER_LINEAR to the next finer level times 2.
+// flow_full (n x H x W x 2) holds the initial flow on entry and the result on exit.
+static int pyramid_batch(fdn_ctx* h, const std::vector<PyrLevel>& lv, const float* R0, float* flow_full, float* M0, float* M1,
+                         PairBatch pb, int H, int W, int winsize, int iters, bool has_initial)
+{
+    const int L = (int)lv.size() - 1;
+    float* fp = (float*)h->flow_pyr.p;
+    const int n = pb.npairs;
+    float* fl = fp + lv[L].f_off;
+    if (has_initial) {
+        if (resize_dev(h, flow_full, H, W, fl, lv[L].h, lv[L].w, 2, n, 3, true, lv[L].scale)) return -1;
+    } else {
+        launch_fill(fl, 0.f, (size_t)n * lv[L].h * lv[L].w * 2, h->stream);
+    }
+    for (int k = L; k >= 0; k--) {
+        float* cur = k == 0 ? flow_full : fp + lv[k].f_off;
+        if (k < L)
+            if (resize_dev(h, fp + lv[k + 1].f_off, lv[k + 1].h, lv[k + 1].w, cur, lv[k].h, lv[k].w, 2, n, 1, true, 2.0)) return -1;
+        const float* Rk = k == 0 ? R0 : (const float*)h->Rpyr.p + lv[k].r_off;
+        run_iterations(h, Rk, cur, M0, M1, pb, lv[k].h, lv[k].w, winsize, iters);
+    }
+    return 0;
+}
+
+static int ensure_flow_pyramid(fdn_ctx* h, std::vector<PyrLevel>& lv, int n)
+{
+    size_t total = 0;
+    for (size_t k = 1; k < lv.size(); k++) { lv[k].f_off = total; total += (size_t)n * lv[k].h * lv[k].w * 2; }
+    return ensure(h, h->flow_pyr, std::max<size_t>(total, 1) * sizeof(float));
 }
 
 static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H, int W, const double* kernel, int K,
@@ -274,8 +413,8 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
         return 0;
     }
     if (H < 2 || W < 2) return fail("optical flow needs images of at least 2x2 pixels, got %dx%d", W, H);
-    if (effective_levels(p->levels, H, W) > 0)
-        return fail("levels > 0 on %dx%d images needs the pyramid path, which this build does not have yet", W, H);
+    std::vector<PyrLevel> lv = pyramid_levels(p->levels, H, W);
+    const bool pyramid = lv.size() > 1;
 
     const int nstack = S + 2 * r;
     if (ensure(h, h->R, (size_t)nstack * 5 * HW * sizeof(float))) return -1;
@@ -285,10 +424,11 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
         ScopedTimer t(h, FDN_TIMER_POLYEXP);
         launch_blur3_polyexp(stack, (float*)h->R.p, nstack, H, W, pc, st);
     }
-    const bool fused = fused_supported(p->winsize, p->iters, H, W) && !getenv("FDN_FORCE_STAGED");
+    if (pyramid && build_R_pyramid(h, stack, nstack, H, W, lv, pc)) return -1;
+    const bool fused = !pyramid && fused_supported(p->winsize, p->iters, H, W) && !getenv("FDN_FORCE_STAGED");
     // targets per batch, bounded by the workspace limit.  fused: two flow buffers (16 B/px);
     // staged: flow 8 B + two M sets 40 B per pixel
-    size_t per_target = HW * (fused ? 16 : 48);
+    size_t per_target = HW * (fused ? 16 : pyramid ? 52 : 48);
     size_t budget = h->ws_limit;
     if (!budget) {
         size_t fre = 0, tot = 0;
@@ -304,6 +444,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
         if (ensure(h, h->flow, (size_t)C * HW * 8)) return -1;
         if (ensure(h, h->M0, (size_t)C * HW * 20)) return -1;
         if (ensure(h, h->M1, (size_t)C * HW * 20)) return -1;
+        if (pyramid && ensure_flow_pyramid(h, lv, C)) return -1;
     }
     float* flow = (float*)h->flow.p;
     float* flowB = flow + (size_t)C * HW * 2; // fused only
@@ -333,7 +474,10 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
                 int d = side == 0 ? -(step + 1) : (step + 1);
                 PairBatch pb{n, r + c0, d};
                 if (!p->chained && step > 0) launch_fill(flow, 0.f, (size_t)n * HW * 2, st);
-                run_iterations(h, R, flow, M0, M1, pb, H, W, p->winsize, p->iters);
+                if (pyramid) {
+                    if (pyramid_batch(h, lv, R, flow, M0, M1, pb, H, W, p->winsize, p->iters, p->chained && step > 0)) return -1;
+                } else
+                    run_iterations(h, R, flow, M0, M1, pb, H, W, p->winsize, p->iters);
                 {
                     ScopedTimer t(h, FDN_TIMER_WARP);
                     launch_warp_accumulate(stack, flow, acc, pb, H, W, kernel[r + d], st);
@@ -458,7 +602,8 @@ FDN_API int fdn_destroy(fdn_handle h)
     if (!h) return 0;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf* bufs[] = {&h->R, &h->M0, &h->M1, &h->flow, &h->stack, &h->sweep_out, &h->vol_a, &h->vol_b, &h->partials, &h->pair};
+    DevBuf* bufs[] = {&h->R, &h->M0, &h->M1, &h->flow, &h->stack, &h->sweep_out, &h->vol_a, &h->vol_b, &h->partials, &h->pair,
+                      &h->Rpyr, &h->flow_pyr, &h->pyr_tmp, &h->area_tab};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     resolve_stamps(h);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -557,8 +702,7 @@ FDN_API int fdn_farneback(fdn_handle h, const float* prev, const float* next, fl
     if (flags & ~FDN_USE_INITIAL_FLOW) return fail("unsupported flags 0x%x (only OPTFLOW_USE_INITIAL_FLOW)", flags);
     fdn_sweep_params p{levels, winsize, iters, poly_n, poly_sigma, 0, 1, 1};
     if (check_params(&p, 1)) return -1;
-    if (effective_levels(levels, H, W) > 0)
-        return fail("levels > 0 on %dx%d images needs the pyramid path, which this build does not have yet", W, H);
+    std::vector<PyrLevel> lv = pyramid_levels(levels, H, W);
     const size_t HW = (size_t)H * W;
     hipStream_t st = h->stream;
     // pair scratch: [prev, next] images | R x2 | flow | M0 | M1
@@ -582,7 +726,12 @@ FDN_API int fdn_farneback(fdn_handle h, const float* prev, const float* next, fl
         ScopedTimer t(h, FDN_TIMER_POLYEXP);
         launch_blur3_polyexp(img, R, 2, H, W, pc, st);
     }
-    run_iterations(h, R, flow, M0, M1, PairBatch{1, 0, 1}, H, W, winsize, iters);
+    if (lv.size() > 1) {
+        if (build_R_pyramid(h, img, 2, H, W, lv, pc)) return -1;
+        if (ensure_flow_pyramid(h, lv, 1)) return -1;
+        if (pyramid_batch(h, lv, R, flow, M0, M1, PairBatch{1, 0, 1}, H, W, winsize, iters, (flags & FDN_USE_INITIAL_FLOW) != 0)) return -1;
+    } else
+        run_iterations(h, R, flow, M0, M1, PairBatch{1, 0, 1}, H, W, winsize, iters);
     FDN_HIP(hipGetLastError());
     {
         ScopedTimer t(h, FDN_TIMER_TRANSFER);

@@ -16,10 +16,12 @@ struct PolyConsts {
 
 void prepare_poly_consts(int n, double sigma, PolyConsts* pc);
 
-// Runtime-tap Gaussian blur kernel (cv::getGaussianKernel, f32), max 63 taps.
+// Runtime-tap Gaussian blur kernel (cv::getGaussianKernel, f32).  Level k of the pyramid uses
+// sigma = (2^k - 1)/2 and ~5 sigma taps: 159 taps at level 6 (images of 2048 pixels and more).
+constexpr int FDN_MAX_BLUR_TAPS = 191;
 struct BlurTaps {
     int n;
-    float k[64];
+    float k[FDN_MAX_BLUR_TAPS + 1];
 };
 void prepare_blur_taps(int n, double sigma, BlurTaps* bt);
 
@@ -81,5 +83,13 @@ void launch_gaussian_blur(const float* in, float* tmp, float* out, int nimg, int
 // multiplied by ps in f64 (the "flow *= scale" of calc).
 void resize_images(const float* in, int sh, int sw, float* out, int dh, int dw, int cn, int nimg,
                    int interp, bool apply_ps, double ps, hipStream_t st);
+
+// true when resize_images can do this (interp, size pair) itself; INTER_AREA with a non-integer
+// shrink ratio needs the table form below
+bool resize_needs_tables(int sh, int sw, int dh, int dw, int interp);
+void resize_area_tab(const float* in, int sh, int sw, float* out, int dh, int dw, int cn, int nimg,
+                     const int* x_si, const float* x_alpha, const int* x_start,
+                     const int* y_si, const float* y_alpha, const int* y_start, bool apply_ps, double ps,
+                     hipStream_t st);
 
 } // namespace fdn

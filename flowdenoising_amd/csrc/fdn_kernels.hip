@@ -490,7 +490,56 @@ __global__ __launch_bounds__(256) void k_resize_area_int(const float* __restrict
         dst[((size_t)dy * dw + dx) * CN + ch] = v;
     }
 }
+// INTER_AREA, any shrink ratio (cv::resizeArea_ with computeResizeAreaTab): per output pixel,
+// rows in table order: buf = sum_k S[sy][sx_k] * alpha_k (f32, left to right, starting from 0),
+// then sum = beta_0 * buf_0, sum += beta_j * buf_j.  Tables: tab_si/tab_alpha with CSR offsets.
+struct AreaTabs {
+    const int* x_si; const float* x_alpha; const int* x_start;   // x_start[dw + 1]
+    const int* y_si; const float* y_alpha; const int* y_start;   // y_start[dh + 1]
+};
+template <int CN>
+__global__ __launch_bounds__(256) void k_resize_area_tab(const float* __restrict__ in, int sh, int sw, float* __restrict__ out,
+                                                         int dh, int dw, AreaTabs t, int apply_ps, double ps)
+{
+    int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    const float* src = in + (size_t)blockIdx.z * sh * sw * CN;
+    float* dst = out + (size_t)blockIdx.z * dh * dw * CN;
+    const int xs = t.x_start[dx], xe = t.x_start[dx + 1], ys = t.y_start[dy], ye = t.y_start[dy + 1];
+#pragma unroll
+    for (int ch = 0; ch < CN; ch++) {
+        float sum = 0.f;
+        for (int j = ys; j < ye; j++) {
+            const float* S = src + (size_t)t.y_si[j] * sw * CN;
+            float buf = 0.f;
+            for (int k = xs; k < xe; k++) buf = buf + S[t.x_si[k] * CN + ch] * t.x_alpha[k];
+            float term = t.y_alpha[j] * buf;
+            sum = j == ys ? term : sum + term;
+        }
+        if (apply_ps) sum = (float)((double)sum * ps);
+        dst[((size_t)dy * dw + dx) * CN + ch] = sum;
+    }
+}
+void resize_area_tab(const float* in, int sh, int sw, float* out, int dh, int dw, int cn, int nimg,
+                     const int* x_si, const float* x_alpha, const int* x_start,
+                     const int* y_si, const float* y_alpha, const int* y_start, bool apply_ps, double ps, hipStream_t st)
+{
+    if (nimg <= 0) return;
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4, nimg);
+    AreaTabs t{x_si, x_alpha, x_start, y_si, y_alpha, y_start};
+    if (cn == 1) hipLaunchKernelGGL(k_resize_area_tab<1>, grid, dim3(256), 0, st, in, sh, sw, out, dh, dw, t, (int)apply_ps, ps);
+    else hipLaunchKernelGGL(k_resize_area_tab<2>, grid, dim3(256), 0, st, in, sh, sw, out, dh, dw, t, (int)apply_ps, ps);
+}
+
 // typed resize entry used by the pyramid driver
+bool resize_needs_tables(int sh, int sw, int dh, int dw, int interp)
+{
+    double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    int isx = (int)scale_x, isy = (int)scale_y;
+    bool integer = fabs(scale_x - isx) < 2.220446049250313e-16 && fabs(scale_y - isy) < 2.220446049250313e-16;
+    return interp == 3 && scale_x >= 1 && scale_y >= 1 && !integer && !(sh == dh && sw == dw);
+}
+
 void resize_images(const float* in, int sh, int sw, float* out, int dh, int dw, int cn, int nimg, int interp,
                    bool apply_ps, double ps, hipStream_t st)
 {

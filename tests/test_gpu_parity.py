@@ -80,6 +80,38 @@ def test_farneback_pair(fdn, oracle, shape, w):
     assert np.abs(got - want).max() < TIGHT_TOL * max(np.abs(want).max(), 1.0)
 
 
+@pytest.mark.parametrize("shape,l", [((128, 160), 1), ((130, 151), 2), ((256, 300), 3), ((97, 300), 3)])
+@pytest.mark.parametrize("w", [5, 15])
+def test_farneback_pyramid(fdn, oracle, shape, l, w):
+    """levels > 0 (par's default is 3; BASELINE configs[4] uses -l 3 -w 15): Gaussian pyramid with
+    INTER_LINEAR images, INTER_AREA initial flow (non-integer ratios for odd sizes), level cropping
+    at 32 pixels."""
+    rng = np.random.default_rng(6)
+    H, W = shape
+    import scipy.ndimage
+    a = _img(rng, H, W, smooth=4.0)
+    b = scipy.ndimage.shift(a.astype(np.float64), (2.3, -1.6), order=3, mode="nearest").astype(np.float32)
+    for init in ("zero", "random"):
+        f0 = np.zeros((H, W, 2), np.float32) if init == "zero" else (rng.standard_normal((H, W, 2)) * 0.7).astype(np.float32)
+        got = fdn.get_flow(b, a, l, w, f0.copy())
+        want = oracle.get_flow(b, a, l, w, f0.copy())
+        assert np.abs(got - want).max() / max(np.abs(want).max(), 1.0) < TIGHT_TOL, (init, np.abs(got - want).max())
+    got = fdn.get_flow_without_prev_flow(b, a, l, w)
+    want = oracle.calcOpticalFlowFarneback(a, b, None, 0.5, l, w, 3, 5, 1.2, 0)
+    assert np.abs(got - want).max() / max(np.abs(want).max(), 1.0) < TIGHT_TOL
+
+
+def test_of_filter_with_pyramid(fdn, oracle):
+    vol = _vol((6, 70, 150), seed=13)
+    k = fdn.get_gaussian_kernel(1.0)
+    got = fdn.OF_filter_along_Z(vol, k, 3, 15, vol.mean())
+    want = oracle.filter_along_axis(vol, 0, k, 3, 15, vol.mean(), nthreads=8)
+    assert rel_err(got, want) < TIGHT_TOL
+    got = fdn.OF_filter(vol, [None, None, k], 2, 5)      # X pass: images 6 x 70 -> no level survives the 32-px crop
+    want = oracle.OF_filter(vol, [None, None, k], 2, 5, nthreads=8)
+    assert rel_err(got, want) < TIGHT_TOL
+
+
 def test_get_flow_updates_prev_flow_in_place(fdn):
     rng = np.random.default_rng(4)
     a, b = _img(rng, 40, 40), _img(rng, 40, 40)
