@@ -1,269 +1,236 @@
 // fdn_fused.hip -- the fast path: one kernel launch = one chain step of the sweep for EVERY
 // target slice of the batch: the whole cv2.calcOpticalFlowFarneback(prev=target,
-// next=neighbour, flow=previous flow, levels=0) (src/flowdenoising_sequential.py:62), the
-// warp of the neighbour (seq:51-57) and the weighted accumulate (seq:107), fused.
+// next=neighbour, flow=previous flow, levels=0, iterations=3) (src/flowdenoising_sequential.py:62),
+// the warp of the neighbour (seq:51-57) and the weighted accumulate (seq:107), fused.
 //
-// Decomposition (wave64, no block-level synchronisation at all):
-//   one wave = one band of 64 image columns of one (target, neighbour) pair, marching down the
-//   rows.  The ITERS flow iterations run as a software pipeline staggered by MH+1 rows:
-//     stage A   row t            : M0 = UpdateMatrices(R0, R1, flow_in)
-//     stage k   row t - k(MH+1)  : vsum_k += f32(M_{k-1}[y+MH] - M_{k-1}[y-MH-1])   (OpenCV's running sum,
-//                                  carried in registers from row 0, hence bit-faithful)
-//                                  box sum across lanes (wave shuffles, f64), 2x2 solve -> flow_k
-//                                  k < ITERS: M_k = UpdateMatrices(R0, R1, flow_k)
-//                                  k = ITERS: store flow, warp the neighbour, accumulate
-//   The 2MH+2 most recent rows of each M_k stay on chip: M0 in a VGPR shift register, the others
-//   in LDS rings private to the wave ([slot][channel][lane] -> conflict-free).  No M ever
-//   reaches HBM; per pair the kernel reads R0, R1 (L2-served re-reads), the chain flow, the
-//   neighbour image and the accumulator once.
-//   Each iteration loses MH columns of validity either side, so a band yields
-//   64 - 2*MH*ITERS output columns (52 for winsize 5); windows that reach outside the image
-//   read the lane of the clamped column, which is BORDER_REPLICATE of the running sums.
-//   In the steady state (all stages active) the step body is one branch-free basic block so
-//   that the three stages' independent memory latencies overlap; the loads that do not depend
-//   on this step's flows (stage A's operands, the R0 rows) are issued before the solves.
+// Decomposition: one 256-thread workgroup = one band of 64 image columns of one (target,
+// neighbour) pair, marching down the rows; its four waves are the four STAGES of a software
+// pipeline staggered by MH+1 rows, and rows stream from stage to stage through LDS:
+//     wave 0 (A)  row t          : M0 = UpdateMatrices(R0, R1, flow_in); also streams the next R0 /
+//                                  R1 rows from HBM into LDS
+//     wave k=1,2  row t - 3k     : vsum_k += f32(M_{k-1}[y+MH] - M_{k-1}[y-MH-1])  (OpenCV's f32-fed
+//                                  vertical running sum, carried in registers from row 0, hence
+//                                  bit-faithful), box sum across lanes (f64), 2x2 solve -> flow_k,
+//                                  M_k = UpdateMatrices(R0, R1, flow_k)
+//     wave 3      row t - 9      : same box sum + solve -> final flow; store it, warp the neighbour
+//                                  image (1/32-px quantised bilinear), accumulate
+//   One s_barrier per row step: everything a wave reads in step t was written in an earlier step,
+//   everything it writes goes to LDS slots nobody reads in step t (ring depths below).
+//   LDS per workgroup (52 KB -> 3 workgroups = 12 waves per CU):
+//     M rings    [3][2MH+3 rows][5 ch][64 lanes]     the matrices never reach HBM
+//     R0 ring    [2MH+3 rows][5][64]                 target expansion rows, loaded once by wave 0
+//     R1 window  [rows t-2(MH+1)-D .. t+D+1][5][64+2D]  neighbour expansion; every stage gathers its
+//                bilinear taps here, so each R1 row is fetched from L2/HBM once per band (a coalesced
+//                row load issued a step ahead) instead of six times by data-dependent gathers that
+//                miss the 32 KB L1.  A flow leaving the window (|d| >= D) makes that wave gather
+//                from global memory for that step.
+//   Splitting the stages over waves keeps each wave's register state small (one running sum set,
+//   no in-register rings), so the dependent chain LDS -> shuffles -> f64 solve -> gather -> matrices
+//   of twelve waves per CU overlaps, where a single wave running all stages was latency-bound.
+//   Each iteration loses MH columns of validity either side: a band yields 64 - 6 MH = 52 output
+//   columns for winsize 5; windows that reach outside the image read the lane of the clamped
+//   column, which is BORDER_REPLICATE of the running sums.
 #include "fdn_internal.h"
 #include "fdn_device.h"
 
 namespace fdn {
 
-template <int MH, int ITERS, bool HAS_FIN>
-__global__ __launch_bounds__(256, 2) void k_farneback_fused(const float* __restrict__ Rstack, const float* __restrict__ stack,
-                                                            const float* __restrict__ flow_in_base, float* __restrict__ flow_out_base,
-                                                            float* __restrict__ acc_base, PairBatch pb, int H, int W,
-                                                            double scale, double weight, int nbands)
+template <int MH, int D, bool HAS_FIN>
+__global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict__ Rstack, const float* __restrict__ stack,
+                                                         const float* __restrict__ flow_in_base, float* __restrict__ flow_out_base,
+                                                         float* __restrict__ acc_base, PairBatch pb, int H, int W,
+                                                         double scale, double weight, int nbands)
 {
-    constexpr int RS = 2 * MH + 2;       // rows of M_k a consumer can still need
+    constexpr int ITERS = 3;
+    constexpr int STEP = MH + 1;                 // row stagger between stages
+    constexpr int RSP = 2 * MH + 3;              // ring depth: newest row being written + 2MH+2 readable
     constexpr int HALO = MH * ITERS;
     constexpr int BW = 64 - 2 * HALO;
-    constexpr int NL = ITERS > 1 ? ITERS - 1 : 1;
-    __shared__ float ringL[4][NL][RS][5][64];
+    constexpr int NRP = (ITERS - 1) * STEP + 2 * D + 2;   // window rows [t-2 STEP-D, t+D] + the one being loaded
+    constexpr int WC = 64 + 2 * D;
+    __shared__ float Mring[ITERS][RSP][5][64];
+    __shared__ float R0ring[RSP][5][64];
+    __shared__ float win[NRP][5][WC];
 
     const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    const long gw = (long)blockIdx.x * 4 + wv;
-    if (gw >= (long)nbands * pb.npairs) return;   // whole wave leaves; nothing below synchronises across waves
+    const int stage = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long gw = blockIdx.x;
     const int b = (int)(gw / nbands);
     const int band = (int)(gw - (long)b * nbands);
-    const int x = band * BW - HALO + lane;
+    const int xb = band * BW - HALO;            // column of lane 0
+    const int x = xb + lane;
     const int xc = clampi(x, 0, W - 1);
-    const bool owner = lane >= HALO && lane < 64 - HALO && x < W;
+    const bool in_img = x == xc;
     const size_t HW = (size_t)H * W;
     const float* R0 = Rstack + (size_t)(pb.t0 + b) * 5 * HW;
     const float* R1 = Rstack + (size_t)(pb.t0 + b + pb.d) * 5 * HW;
-    const float* img1 = stack + (size_t)(pb.t0 + b + pb.d) * HW;
-    const float2* flow_in = HAS_FIN ? (const float2*)flow_in_base + (size_t)b * HW : nullptr;
-    float2* flow_out = flow_out_base ? (float2*)flow_out_base + (size_t)b * HW : nullptr;
-    float* acc = acc_base + (size_t)b * HW;
-    float (*ring)[RS][5][64] = ringL[wv];
     const float bxx = border_factor(xc, W);
     const bool xdamp = border_test(xc, W);
+    const int xw0 = xb - D;                      // image column of window column 0
 
     // Lanes the horizontal window of this lane reads: the lane that owns column clamp(x+j).
     // (Replica lanes outside the image are never read: a replica's own window is shifted, so
     // from the second iteration on it would no longer equal the border column it stands for.)
     int src[2 * MH + 1];
 #pragma unroll
-    for (int j = -MH; j <= MH; j++) src[j + MH] = clampi(clampi(x + j, 0, W - 1) - (x - lane), 0, 63);
-
-    float ring0[RS][5];       // M0 rows: ring0[j] = row clamp(newest - j)
-    double vs[ITERS][5];
-#pragma unroll
-    for (int j = 0; j < RS; j++)
-#pragma unroll
-        for (int c = 0; c < 5; c++) ring0[j][c] = 0.f;
-#pragma unroll
-    for (int k = 0; k < ITERS; k++)
-#pragma unroll
-        for (int c = 0; c < 5; c++) vs[k][c] = 0.;
+    for (int j = -MH; j <= MH; j++) src[j + MH] = clampi(clampi(x + j, 0, W - 1) - xb, 0, 63);
 
     auto row_factor = [&](int y, float& by0, float& by1) {
         by0 = y < 5 ? (y < 2 ? 0.14f : 0.4472f) : 1.f;
         by1 = y >= H - 5 ? (H - y - 1 < 2 ? 0.14f : 0.4472f) : 1.f;
     };
+    // Bilinear taps for a stage working on row ys.  `need`: lanes whose result is used.  Fast path:
+    // every needed lane's 2x2 footprint lies in window rows [ys-D, ys+D] and the window's columns.
+    auto gather = [&](int ys, int x1, int y1, bool need, GatherTaps& g) __attribute__((always_inline)) {
+        const int x1c = clampi(x1, 0, W - 2), y1c = clampi(y1, 0, H - 2);
+        int col = x1c - xw0;
+        const int dy = y1c - (ys - D);
+        const bool inwin = col >= 0 && col <= WC - 2 && dy >= 0 && dy <= 2 * D - 1;
+        if (__builtin_expect(__any(need && !inwin), 0)) {
+            gather_R1(R1, HW, H, W, x1, y1, g);
+            return;
+        }
+        int r0w = y1c;
+        if (!(need && inwin)) { col = lane + D; r0w = clampi(ys, 0, H - 2); }   // lanes nobody reads: stay inside the window
+        const int s0 = r0w % NRP;
+        const int s1 = s0 + 1 == NRP ? 0 : s0 + 1;
+        const float* q0 = &win[s0][0][col];
+        const float* q1 = &win[s1][0][col];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            g.t0[c].a = q0[c * WC]; g.t0[c].b = q0[c * WC + 1];
+            g.t1[c].a = q1[c * WC]; g.t1[c].b = q1[c * WC + 1];
+        }
+    };
+    auto update_matrices = [&](int ys, float2 f, const float r0[5], bool need, float mm[5]) __attribute__((always_inline)) {
+        int x1, y1; float fx, fy;
+        flow_target(xc, ys, f.x, f.y, x1, y1, fx, fy);
+        GatherTaps g;
+        gather(ys, x1, y1, need, g);
+        float by0, by1;
+        row_factor(ys, by0, by1);
+        finish_M(r0, g, H, W, x1, y1, fx, fy, f.x, f.y, bxx, by0, by1, xdamp || border_test(ys, H), mm);
+    };
 
-    // ---- general step: any stage may be inactive (pipeline fill / drain) ------------------
-    auto general_step = [&](int t) __attribute__((always_inline)) {
-        // consumers first (highest stage first): every ring is read before this step overwrites it
+    const int T = H + ITERS * STEP;
+
+    if (stage == 0) {
+        // ===== wave 0: stage A + the R0 / R1 row streams ==========================================
+        const float2* flow_in = HAS_FIN ? (const float2*)flow_in_base + (size_t)b * HW : nullptr;
+        const int wcol0 = clampi(xw0 + lane, 0, W - 1);        // image columns this lane loads into the window
+        const int wcol1 = clampi(xw0 + 64 + lane, 0, W - 1);
+        auto load_window_row = [&](int v, float w0[5], float w1[5]) __attribute__((always_inline)) {
+            const float* p = R1 + (size_t)v * W;
 #pragma unroll
-        for (int k = ITERS; k >= 1; k--) {
-            const int y = t - k * (MH + 1);
-            if (y < 0 || y >= H) continue;            // wave-uniform
-            float mnew[5], mold[5];
-            if (k == 1) {
-                if (y == 0) { // vsum before row 0: f32(M[0]*(m+2)) + rows 1..m-1   (ring0[j] = row MH - j here)
+            for (int c = 0; c < 5; c++) { w0[c] = p[c * HW + wcol0]; w1[c] = p[c * HW + wcol1]; }
+        };
+        auto store_window_row = [&](int v, const float w0[5], const float w1[5]) __attribute__((always_inline)) {
+            const int s = v % NRP;
 #pragma unroll
-                    for (int c = 0; c < 5; c++) {
-                        double v = (double)(ring0[MH][c] * (float)(MH + 2));
+            for (int c = 0; c < 5; c++) win[s][c][lane] = w0[c];
+            if (lane < 2 * D) {
 #pragma unroll
-                        for (int yy = 1; yy < MH; yy++) v += (double)ring0[MH - yy][c];
-                        vs[0][c] = v;
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < 5; c++) { mnew[c] = ring0[0][c]; mold[c] = ring0[RS - 1][c]; }
-            } else {
-                float (*rg)[5][64] = ring[k - 2];
-                if (y == 0) {
-#pragma unroll
-                    for (int c = 0; c < 5; c++) {
-                        double v = (double)(rg[0][c][lane] * (float)(MH + 2));
-#pragma unroll
-                        for (int yy = 1; yy < MH; yy++) v += (double)rg[(yy < H - 1 ? yy : H - 1) % RS][c][lane];
-                        vs[k - 1][c] = v;
-                    }
-                }
-                const int rn = (y + MH < H - 1 ? y + MH : H - 1) % RS;
-                const int ro = (y - MH - 1 > 0 ? y - MH - 1 : 0) % RS;
-#pragma unroll
-                for (int c = 0; c < 5; c++) { mnew[c] = rg[rn][c][lane]; mold[c] = rg[ro][c][lane]; }
+                for (int c = 0; c < 5; c++) win[s][c][64 + lane] = w1[c];
             }
+        };
+        {   // rows 0..D before the first step
+            float w0[5], w1[5];
+            for (int v = 0; v <= (D < H - 1 ? D : H - 1); v++) { load_window_row(v, w0, w1); store_window_row(v, w0, w1); }
+        }
+        // operands of row 0, then always one row ahead
+        float2 fN = HAS_FIN ? flow_in[xc] : make_float2(0.f, 0.f);
+        float r0N[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) r0N[c] = R0[c * HW + xc];
+        __syncthreads();
+        for (int t = 0; t < T; t++) {
+            if (t < H) {
+                const float2 f = fN;
+                float r0[5];
+#pragma unroll
+                for (int c = 0; c < 5; c++) r0[c] = r0N[c];
+                const int tn = t + 1 < H ? t + 1 : H - 1;
+                const size_t on = (size_t)tn * W + xc;
+                fN = HAS_FIN ? flow_in[on] : make_float2(0.f, 0.f);
+#pragma unroll
+                for (int c = 0; c < 5; c++) r0N[c] = R0[c * HW + on];
+                const int vnext = t + D + 1;                 // window row the next step needs
+                float wl0[5], wl1[5];
+                load_window_row(vnext < H ? vnext : H - 1, wl0, wl1);
+                const int s = t % RSP;
+#pragma unroll
+                for (int c = 0; c < 5; c++) R0ring[s][c][lane] = r0[c];
+                float mm[5];
+                update_matrices(t, f, r0, in_img, mm);
+#pragma unroll
+                for (int c = 0; c < 5; c++) Mring[0][s][c][lane] = mm[c];
+                if (vnext < H) store_window_row(vnext, wl0, wl1);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ===== waves 1..3: iteration `stage` =============================================================
+    const int k = stage;
+    float (*Min)[5][64] = Mring[k - 1];
+    double vs[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) vs[c] = 0.;
+    const bool owner = lane >= HALO && lane < 64 - HALO && x < W;
+    const float* img1 = stack + (size_t)(pb.t0 + b + pb.d) * HW;
+    float2* flow_out = flow_out_base ? (float2*)flow_out_base + (size_t)b * HW : nullptr;
+    float* acc = acc_base + (size_t)b * HW;
+    const bool need = in_img && lane >= k * MH && lane < 64 - k * MH;   // lanes whose M_k feeds a valid output
+
+    __syncthreads();
+    for (int t = 0; t < T; t++) {
+        const int y = t - k * STEP;
+        if (y >= 0 && y < H) {
+            // final stage: the accumulator does not depend on this step's flow: load it first
+            float acc_old = 0.f;
+            const size_t o = (size_t)y * W + xc;
+            if (k == ITERS) acc_old = acc[o];
+            if (y == 0) { // vsum before row 0: f32(M[0]*(m+2)) + rows 1..m-1 (clamped)
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    double v = (double)(Min[0][c][lane] * (float)(MH + 2));
+#pragma unroll
+                    for (int yy = 1; yy < MH; yy++) v += (double)Min[(yy < H - 1 ? yy : H - 1) % RSP][c][lane];
+                    vs[c] = v;
+                }
+            }
+            const int rn = (y + MH < H - 1 ? y + MH : H - 1) % RSP;
+            const int ro = (y - MH - 1 > 0 ? y - MH - 1 : 0) % RSP;
             double a[5];
 #pragma unroll
             for (int c = 0; c < 5; c++) {
-                vs[k - 1][c] += (double)(mnew[c] - mold[c]);
+                vs[c] += (double)(Min[rn][c][lane] - Min[ro][c][lane]);
                 double s = 0;
 #pragma unroll
-                for (int j = 0; j <= 2 * MH; j++) s += j == MH ? vs[k - 1][c] : __shfl(vs[k - 1][c], src[j], 64);
+                for (int j = 0; j <= 2 * MH; j++) s += j == MH ? vs[c] : __shfl(vs[c], src[j], 64);
                 a[c] = s;
             }
             const float2 f = solve_flow(a, scale);
-            const size_t o = (size_t)y * W + xc;
             if (k < ITERS) {
+                const int s = y % RSP;
                 float r0[5], mm[5];
 #pragma unroll
-                for (int c = 0; c < 5; c++) r0[c] = R0[c * HW + o];
-                compute_M(r0, R1, HW, H, W, xc, y, f.x, f.y, mm);
+                for (int c = 0; c < 5; c++) r0[c] = R0ring[s][c][lane];
+                update_matrices(y, f, r0, need, mm);
 #pragma unroll
-                for (int c = 0; c < 5; c++) ring[k - 1][y % RS][c][lane] = mm[c];
-            } else if (owner) {
-                if (flow_out) flow_out[o] = f;
-                float v = remap_sample(img1, H, W, x, y, f);
-                acc[o] = (float)((double)acc[o] + (double)v * weight);
-            }
-        }
-        // stage A: push M0 row t (below the image: a replica of the last row, so that
-        // ring0[j] always holds row clamp(newest - j))
-#pragma unroll
-        for (int j = RS - 1; j >= 1; j--)
-#pragma unroll
-            for (int c = 0; c < 5; c++) ring0[j][c] = ring0[j - 1][c];
-        if (t < H) {
-            const size_t o = (size_t)t * W + xc;
-            float2 f = HAS_FIN ? flow_in[o] : make_float2(0.f, 0.f);
-            float r0[5], mm[5];
-#pragma unroll
-            for (int c = 0; c < 5; c++) r0[c] = R0[c * HW + o];
-            compute_M(r0, R1, HW, H, W, xc, t, f.x, f.y, mm);
-#pragma unroll
-            for (int c = 0; c < 5; c++) ring0[0][c] = mm[c];
-            if (t == 0) { // rows above the image replicate row 0
-#pragma unroll
-                for (int j = 1; j < RS; j++)
-#pragma unroll
-                    for (int c = 0; c < 5; c++) ring0[j][c] = mm[c];
-            }
-        }
-    };
-
-    const int T = H + ITERS * (MH + 1);
-    // steady state: every stage active, no row clamps: (ITERS+1)(MH+1) <= t <= H-1
-    const int ts0 = (ITERS + 1) * (MH + 1);
-    const int ts1 = H; // exclusive
-    int t = 0;
-    for (; t < T && (t < ts0 || ts0 >= ts1); t++) general_step(t);
-
-    if (t < ts1) {
-        int slot[ITERS + 1]; // slot[k] = y_k % RS (k >= 1)
-#pragma unroll
-        for (int k = 1; k <= ITERS; k++) slot[k] = (t - k * (MH + 1)) % RS;
-
-        for (; t < ts1; t++) {
-            // ---- loads that depend on nothing computed in this step go first: stage A's
-            //      operands (the only ones that miss to HBM) and the R0 rows of the other stages
-            const size_t oA = (size_t)t * W + xc;
-            const float2 fA = HAS_FIN ? flow_in[oA] : make_float2(0.f, 0.f);
-            float r0A[5];
-#pragma unroll
-            for (int c = 0; c < 5; c++) r0A[c] = R0[c * HW + oA];
-            int x1A, y1A; float fxA, fyA;
-            flow_target(xc, t, fA.x, fA.y, x1A, y1A, fxA, fyA);
-            GatherTaps gA;
-            gather_R1(R1, HW, H, W, x1A, y1A, gA);
-            float r0k[ITERS][5];
-#pragma unroll
-            for (int k = 1; k < ITERS; k++) {
-                const size_t o = (size_t)(t - k * (MH + 1)) * W + xc;
-#pragma unroll
-                for (int c = 0; c < 5; c++) r0k[k][c] = R0[c * HW + o];
-            }
-            const int yl = t - ITERS * (MH + 1);
-            const size_t ol = (size_t)yl * W + xc;
-            const float acc_old = acc[ol];
-            // ---- running sums, box sums, solves for all stages --------------------------
-            float2 f[ITERS + 1];
-#pragma unroll
-            for (int k = 1; k <= ITERS; k++) {
-                float mnew[5], mold[5];
-                if (k == 1) {
-#pragma unroll
-                    for (int c = 0; c < 5; c++) { mnew[c] = ring0[0][c]; mold[c] = ring0[RS - 1][c]; }
-                } else {
-                    // rows y+MH and y-MH-1 of M_{k-1}: slots (y+MH)%RS and (y+MH+1)%RS
-                    int rn = slot[k] + MH; rn = rn >= RS ? rn - RS : rn;
-                    int ro = rn + 1 == RS ? 0 : rn + 1;
-#pragma unroll
-                    for (int c = 0; c < 5; c++) { mnew[c] = ring[k - 2][rn][c][lane]; mold[c] = ring[k - 2][ro][c][lane]; }
+                for (int c = 0; c < 5; c++) Mring[k < ITERS ? k : 0][s][c][lane] = mm[c];
+            } else {
+                const float warped = remap_sample(img1, H, W, xc, y, f);
+                const float acc_new = (float)((double)acc_old + (double)warped * weight);
+                if (owner) {
+                    if (flow_out) flow_out[o] = f;
+                    acc[o] = acc_new;
                 }
-                double a[5];
-#pragma unroll
-                for (int c = 0; c < 5; c++) {
-                    vs[k - 1][c] += (double)(mnew[c] - mold[c]);
-                    double s = 0;
-#pragma unroll
-                    for (int j = 0; j <= 2 * MH; j++) s += j == MH ? vs[k - 1][c] : __shfl(vs[k - 1][c], src[j], 64);
-                    a[c] = s;
-                }
-                f[k] = solve_flow(a, scale);
             }
-            // ---- loads that depend on the new flows ---------------------------------------
-            GatherTaps gk[ITERS];
-            int x1k[ITERS], y1k[ITERS]; float fxk[ITERS], fyk[ITERS];
-#pragma unroll
-            for (int k = 1; k < ITERS; k++) {
-                flow_target(xc, t - k * (MH + 1), f[k].x, f[k].y, x1k[k], y1k[k], fxk[k], fyk[k]);
-                gather_R1(R1, HW, H, W, x1k[k], y1k[k], gk[k]);
-            }
-            const float warped = remap_sample(img1, H, W, xc, yl, f[ITERS]);
-            // ---- matrices ------------------------------------------------------------------
-            float by0, by1, mm[5];
-            row_factor(t, by0, by1);
-            finish_M(r0A, gA, H, W, x1A, y1A, fxA, fyA, fA.x, fA.y, bxx, by0, by1, xdamp || border_test(t, H), mm);
-#pragma unroll
-            for (int j = RS - 1; j >= 1; j--)
-#pragma unroll
-                for (int c = 0; c < 5; c++) ring0[j][c] = ring0[j - 1][c];
-#pragma unroll
-            for (int c = 0; c < 5; c++) ring0[0][c] = mm[c];
-#pragma unroll
-            for (int k = 1; k < ITERS; k++) {
-                row_factor(t - k * (MH + 1), by0, by1);
-                finish_M(r0k[k], gk[k], H, W, x1k[k], y1k[k], fxk[k], fyk[k], f[k].x, f[k].y, bxx, by0, by1,
-                         xdamp || border_test(t - k * (MH + 1), H), mm);
-#pragma unroll
-                for (int c = 0; c < 5; c++) ring[k - 1][slot[k]][c][lane] = mm[c];
-            }
-            // ---- outputs (computed outside the predicate so the loads are not sunk into it) ---
-            const float acc_new = (float)((double)acc_old + (double)warped * weight);
-            if (owner) {
-                if (flow_out) flow_out[ol] = f[ITERS];
-                acc[ol] = acc_new;
-            }
-#pragma unroll
-            for (int k = 1; k <= ITERS; k++) slot[k] = slot[k] + 1 == RS ? 0 : slot[k] + 1;
         }
+        __syncthreads();
     }
-    for (; t < T; t++) general_step(t);
 }
 
 bool fused_supported(int winsize, int iters, int H, int W)
@@ -276,17 +243,17 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
 {
     if (pb.npairs <= 0) return;
     (void)iters;
-    constexpr int MH = 2, ITERS = 3;
-    const int BW = 64 - 2 * MH * ITERS;
+    constexpr int MH = 2, D = 2;
+    const int BW = 64 - 2 * MH * 3;
     int nbands = (W + BW - 1) / BW;
-    long waves = (long)nbands * pb.npairs;
+    long blocks = (long)nbands * pb.npairs;
     double scale = 1. / ((double)winsize * winsize);
-    dim3 grid((unsigned)((waves + 3) / 4));
+    dim3 grid((unsigned)blocks);
     if (flow_in)
-        hipLaunchKernelGGL((k_farneback_fused<MH, ITERS, true>), grid, dim3(256), 0, st,
+        hipLaunchKernelGGL((k_farneback_fused<MH, D, true>), grid, dim3(256), 0, st,
                            Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands);
     else
-        hipLaunchKernelGGL((k_farneback_fused<MH, ITERS, false>), grid, dim3(256), 0, st,
+        hipLaunchKernelGGL((k_farneback_fused<MH, D, false>), grid, dim3(256), 0, st,
                            Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands);
 }
 
