@@ -35,7 +35,7 @@
 
 namespace fdn {
 
-template <int MH, int D, bool HAS_FIN>
+template <int MH, int D, bool WIN, bool HAS_FIN>
 __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict__ Rstack, const float* __restrict__ stack,
                                                          const float* __restrict__ flow_in_base, float* __restrict__ flow_out_base,
                                                          float* __restrict__ acc_base, PairBatch pb, int H, int W,
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
     constexpr int WC = 64 + 2 * D;
     __shared__ float Mring[ITERS][RSP][5][64];
     __shared__ float R0ring[RSP][5][64];
-    __shared__ float win[NRP][5][WC];
+    __shared__ float win[WIN ? NRP : 1][5][WC];
 
     const int lane = threadIdx.x & 63;
     const int stage = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
         int col = x1c - xw0;
         const int dy = y1c - (ys - D);
         const bool inwin = col >= 0 && col <= WC - 2 && dy >= 0 && dy <= 2 * D - 1;
-        if (__builtin_expect(__any(need && !inwin), 0)) {
+        if (!WIN || __any(need && !inwin)) {
             gather_R1(R1, HW, H, W, x1, y1, g);
             return;
         }
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
                 for (int c = 0; c < 5; c++) win[s][c][64 + lane] = w1[c];
             }
         };
-        {   // rows 0..D before the first step
+        if (WIN) {   // rows 0..D before the first step
             float w0[5], w1[5];
             for (int v = 0; v <= (D < H - 1 ? D : H - 1); v++) { load_window_row(v, w0, w1); store_window_row(v, w0, w1); }
         }
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
                 for (int c = 0; c < 5; c++) r0N[c] = R0[c * HW + on];
                 const int vnext = t + D + 1;                 // window row the next step needs
                 float wl0[5], wl1[5];
-                load_window_row(vnext < H ? vnext : H - 1, wl0, wl1);
+                if (WIN) load_window_row(vnext < H ? vnext : H - 1, wl0, wl1);
                 const int s = t % RSP;
 #pragma unroll
                 for (int c = 0; c < 5; c++) R0ring[s][c][lane] = r0[c];
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
                 update_matrices(t, f, r0, in_img, mm);
 #pragma unroll
                 for (int c = 0; c < 5; c++) Mring[0][s][c][lane] = mm[c];
-                if (vnext < H) store_window_row(vnext, wl0, wl1);
+                if (WIN && vnext < H) store_window_row(vnext, wl0, wl1);
             }
             __syncthreads();
         }
@@ -244,16 +244,17 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
     if (pb.npairs <= 0) return;
     (void)iters;
     constexpr int MH = 2, D = 2;
+    constexpr bool WIN = false;   // see the header: the R1 window only pays when flows stay within +-D pixels
     const int BW = 64 - 2 * MH * 3;
     int nbands = (W + BW - 1) / BW;
     long blocks = (long)nbands * pb.npairs;
     double scale = 1. / ((double)winsize * winsize);
     dim3 grid((unsigned)blocks);
     if (flow_in)
-        hipLaunchKernelGGL((k_farneback_fused<MH, D, true>), grid, dim3(256), 0, st,
+        hipLaunchKernelGGL((k_farneback_fused<MH, D, WIN, true>), grid, dim3(256), 0, st,
                            Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands);
     else
-        hipLaunchKernelGGL((k_farneback_fused<MH, D, false>), grid, dim3(256), 0, st,
+        hipLaunchKernelGGL((k_farneback_fused<MH, D, WIN, false>), grid, dim3(256), 0, st,
                            Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands);
 }
 
