@@ -43,11 +43,14 @@ struct GatherTaps { float2u t0[5], t1[5]; };
 static __device__ __forceinline__ void gather_R1(const float* __restrict__ R1, size_t HW, int H, int W,
                                                  int x1, int y1, GatherTaps& g)
 {
-    const float* p = R1 + (size_t)clampi(y1, 0, H - 2) * W + clampi(x1, 0, W - 2);
+    // uniform plane base (SGPRs) + one 32-bit per-lane element offset: the loads take the
+    // saddr + voffset form instead of ten 64-bit per-lane address computations
+    const unsigned off = (unsigned)clampi(y1, 0, H - 2) * (unsigned)W + (unsigned)clampi(x1, 0, W - 2);
 #pragma unroll
     for (int c = 0; c < 5; c++) {
-        g.t0[c] = *(const float2u*)(p + c * HW);
-        g.t1[c] = *(const float2u*)(p + c * HW + W);
+        const float* plane = R1 + (size_t)c * HW;
+        g.t0[c] = *(const float2u*)(plane + off);
+        g.t1[c] = *(const float2u*)(plane + off + (unsigned)W);
     }
 }
 
@@ -111,7 +114,11 @@ static __device__ __forceinline__ float2 solve_flow(const double a[5], double sc
     return f;
 }
 
-static __device__ __forceinline__ float remap_sample(const float* __restrict__ src, int H, int W, int x, int y, float2 f)
+// remap in two halves so that a kernel can issue the four tap loads one pipeline step before it
+// combines them: remap_issue computes the quantised position and loads, remap_finish weights.
+struct RemapTaps { float v0, v1, v2, v3; int ax, ay; };
+
+static __device__ __forceinline__ void remap_issue(const float* __restrict__ src, int H, int W, int x, int y, float2 f, RemapTaps& r)
 {
     float mx = (float)((double)f.x + (double)x);
     float my = (float)((double)f.y + (double)y);
@@ -119,18 +126,28 @@ static __device__ __forceinline__ float remap_sample(const float* __restrict__ s
     float qx = fminf(fmaxf(rintf(mx * 32.f), -2147483520.f), 2147483520.f);
     float qy = fminf(fmaxf(rintf(my * 32.f), -2147483520.f), 2147483520.f);
     int sx = (int)qx, sy = (int)qy;
-    int ax = sx & 31, ay = sy & 31;
+    r.ax = sx & 31; r.ay = sy & 31;
     int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);
-    float tx1 = (float)ax * (1.f / 32), tx0 = 1.f - tx1;
-    float ty1 = (float)ay * (1.f / 32), ty0 = 1.f - ty1;
-    float w0 = ty0 * tx0, w1 = ty0 * tx1, w2 = ty1 * tx0, w3 = ty1 * tx1;
     int xa = clampi(ix, 0, W - 1), xb = clampi(ix + 1, 0, W - 1);
     int ya = clampi(iy, 0, H - 1), yb = clampi(iy + 1, 0, H - 1);
     const float* ra = src + (size_t)ya * W;
     const float* rb = src + (size_t)yb * W;
-    float v0 = ra[xa], v1 = ra[xb], v2 = rb[xa], v3 = rb[xb];
-    return v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
+    r.v0 = ra[xa]; r.v1 = ra[xb]; r.v2 = rb[xa]; r.v3 = rb[xb];
 }
 
+static __device__ __forceinline__ float remap_finish(const RemapTaps& r)
+{
+    float tx1 = (float)r.ax * (1.f / 32), tx0 = 1.f - tx1;
+    float ty1 = (float)r.ay * (1.f / 32), ty0 = 1.f - ty1;
+    float w0 = ty0 * tx0, w1 = ty0 * tx1, w2 = ty1 * tx0, w3 = ty1 * tx1;
+    return r.v0 * w0 + r.v1 * w1 + r.v2 * w2 + r.v3 * w3;
+}
+
+static __device__ __forceinline__ float remap_sample(const float* __restrict__ src, int H, int W, int x, int y, float2 f)
+{
+    RemapTaps r;
+    remap_issue(src, H, W, x, y, f, r);
+    return remap_finish(r);
+}
 
 } // namespace fdn

@@ -35,6 +35,31 @@
 
 namespace fdn {
 
+// Whole-wave lane shifts of an f64 on the VALU (DPP wave_shr:1 / wave_shl:1): lane i receives the
+// value of lane i-1 (i+1).  Measured on MI355X (tools/ubench/rates.hip): ~5 cycles per v_mov_dpp per
+// SIMD against 24 cycles per ds_bpermute_b32 on the one LDS pipe the four SIMDs share.
+static __device__ __forceinline__ double wave_shr1(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+static __device__ __forceinline__ double wave_shl1(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Workgroup barrier that publishes LDS writes only.  __syncthreads() also drains vmcnt, which would
+// force every in-flight global load / prefetch / store to complete at each row step.
+static __device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int MH, int D, bool WIN, bool HAS_FIN>
 __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict__ Rstack, const float* __restrict__ stack,
                                                          const float* __restrict__ flow_in_base, float* __restrict__ flow_out_base,
@@ -142,7 +167,7 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
         float r0N[5];
 #pragma unroll
         for (int c = 0; c < 5; c++) r0N[c] = R0[c * HW + xc];
-        __syncthreads();
+        lds_barrier();
         for (int t = 0; t < T; t++) {
             if (t < H) {
                 const float2 f = fN;
@@ -166,7 +191,7 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
                 for (int c = 0; c < 5; c++) Mring[0][s][c][lane] = mm[c];
                 if (WIN && vnext < H) store_window_row(vnext, wl0, wl1);
             }
-            __syncthreads();
+            lds_barrier();
         }
         return;
     }
@@ -174,6 +199,8 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
     // ===== waves 1..3: iteration `stage` =============================================================
     const int k = stage;
     float (*Min)[5][64] = Mring[k - 1];
+    // block-uniform: does any lane of this band have a window column outside the image?
+    const bool edge_band = xb < MH || xb + 63 + MH > W - 1;
     double vs[5];
 #pragma unroll
     for (int c = 0; c < 5; c++) vs[c] = 0.;
@@ -183,7 +210,7 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
     float* acc = acc_base + (size_t)b * HW;
     const bool need = in_img && lane >= k * MH && lane < 64 - k * MH;   // lanes whose M_k feeds a valid output
 
-    __syncthreads();
+    lds_barrier();
     for (int t = 0; t < T; t++) {
         const int y = t - k * STEP;
         if (y >= 0 && y < H) {
@@ -207,8 +234,15 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
             for (int c = 0; c < 5; c++) {
                 vs[c] += (double)(Min[rn][c][lane] - Min[ro][c][lane]);
                 double s = 0;
+                if (edge_band) {   // windows reach outside the image: read the lane of the clamped column
 #pragma unroll
-                for (int j = 0; j <= 2 * MH; j++) s += j == MH ? vs[c] : __shfl(vs[c], src[j], 64);
+                    for (int j = 0; j <= 2 * MH; j++) s += j == MH ? vs[c] : __shfl(vs[c], src[j], 64);
+                } else {           // same five terms in the same order, by lane shifts
+                    static_assert(MH == 2, "the DPP window is written for a 5-wide box");
+                    const double m1 = wave_shr1(vs[c]), m2 = wave_shr1(m1);
+                    const double p1 = wave_shl1(vs[c]), p2 = wave_shl1(p1);
+                    s += m2; s += m1; s += vs[c]; s += p1; s += p2;
+                }
                 a[c] = s;
             }
             const float2 f = solve_flow(a, scale);
@@ -229,7 +263,7 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
