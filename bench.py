@@ -64,11 +64,27 @@ def algorithmic_bytes(timers, shape, K, axes):
     bytes_per_launch = per_px[name] * nvox
     avg_ms = ms / cnt
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": {"fused": "k_farneback_fused", "update_flow": "k_update_flow"}[name],
+    traffic, traffic_note = measured_traffic(name, nvox)
+    return {"bound": "hbm", "kernel": {"fused": "k_farneback_fused", "update_flow": "k_update_flow_scan"}[name],
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
             "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(avg_ms, 4),
             "launches": cnt}
+
+
+def measured_traffic(name, nvox):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/), scaled to
+    this run's pixels per launch; None when no PMC data exists for the kernel."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if name != "fused" or not os.path.exists(path):
+        return None, "no PMC pass for this kernel"
+    with open(path) as f:
+        t = json.load(f)
+    scale = nvox / t["pixels_per_launch"]
+    return round(t["bytes_per_launch_low"] * scale), (
+        f"(FETCH_SIZE + WRITE_SIZE) x 1024 per launch from {os.path.basename(path)}; read side is a lower bound "
+        f"(gfx950 FETCH_SIZE undercounts by up to 2x, uncalibrated for 4/8-B-per-lane loads): true value in "
+        f"[{t['bytes_per_launch_low'] * scale:.3e}, {t['bytes_per_launch_high'] * scale:.3e}] B")
 
 
 def cpu_baseline(vol_t, shape, kernel, mean, n_targets):
