@@ -32,6 +32,7 @@
 //   column, which is BORDER_REPLICATE of the running sums.
 #include "fdn_internal.h"
 #include "fdn_device.h"
+#include <stdlib.h>
 
 namespace fdn {
 
@@ -60,7 +61,7 @@ static __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int MH, int D, bool WIN, bool HAS_FIN>
+template <int MH, int D, bool WIN, bool R0L, bool HAS_FIN>
 __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict__ Rstack, const float* __restrict__ stack,
                                                          const float* __restrict__ flow_in_base, float* __restrict__ flow_out_base,
                                                          float* __restrict__ acc_base, PairBatch pb, int H, int W,
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
     constexpr int NRP = (ITERS - 1) * STEP + 2 * D + 2;   // window rows [t-2 STEP-D, t+D] + the one being loaded
     constexpr int WC = 64 + 2 * D;
     __shared__ float Mring[ITERS][RSP][5][64];
-    __shared__ float R0ring[RSP][5][64];
+    __shared__ float R0ring[R0L ? RSP : 1][5][64];
     __shared__ float win[WIN ? NRP : 1][5][WC];
 
     const int lane = threadIdx.x & 63;
@@ -183,8 +184,10 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
                 float wl0[5], wl1[5];
                 if (WIN) load_window_row(vnext < H ? vnext : H - 1, wl0, wl1);
                 const int s = t % RSP;
+                if (R0L) {
 #pragma unroll
-                for (int c = 0; c < 5; c++) R0ring[s][c][lane] = r0[c];
+                    for (int c = 0; c < 5; c++) R0ring[s][c][lane] = r0[c];
+                }
                 float mm[5];
                 update_matrices(t, f, r0, in_img, mm);
 #pragma unroll
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
                 const int s = y % RSP;
                 float r0[5], mm[5];
 #pragma unroll
-                for (int c = 0; c < 5; c++) r0[c] = R0ring[s][c][lane];
+                for (int c = 0; c < 5; c++) r0[c] = R0L ? R0ring[s][c][lane] : R0[c * HW + o];
                 update_matrices(y, f, r0, need, mm);
 #pragma unroll
                 for (int c = 0; c < 5; c++) Mring[k < ITERS ? k : 0][s][c][lane] = mm[c];
@@ -284,12 +287,18 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
     long blocks = (long)nbands * pb.npairs;
     double scale = 1. / ((double)winsize * winsize);
     dim3 grid((unsigned)blocks);
-    if (flow_in)
-        hipLaunchKernelGGL((k_farneback_fused<MH, D, WIN, true>), grid, dim3(256), 0, st,
-                           Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands);
-    else
-        hipLaunchKernelGGL((k_farneback_fused<MH, D, WIN, false>), grid, dim3(256), 0, st,
-                           Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands);
+    // R0 ring in LDS (35.8 KB, 4 workgroups per CU, fewer L2 requests: faster when the grid fills the
+    // chip several times over) or R0 re-read from L2 by stages 1 and 2 (26.9 KB, 6 workgroups per CU):
+    // a small batch -- e.g. the 64-slice slab of an 8-GPU run, 1280 workgroups -- then runs in one
+    // wave of workgroups instead of one and a quarter.
+    const char* env = getenv("FDN_R0_RING");
+    const bool r0l = env ? atoi(env) != 0 : blocks > 256 * 6;
+#define FDN_LAUNCH(R0L, FIN)                                                                                   \
+    hipLaunchKernelGGL((k_farneback_fused<MH, D, WIN, R0L, FIN>), grid, dim3(256), 0, st, Rstack, stack, flow_in, \
+                       flow_out, acc, pb, H, W, scale, weight, nbands)
+    if (r0l) { if (flow_in) FDN_LAUNCH(true, true); else FDN_LAUNCH(true, false); }
+    else     { if (flow_in) FDN_LAUNCH(false, true); else FDN_LAUNCH(false, false); }
+#undef FDN_LAUNCH
 }
 
 } // namespace fdn

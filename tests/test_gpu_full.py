@@ -105,6 +105,23 @@ def test_wide_window_uses_the_staged_path(fdn, oracle):
     assert rel_err(got, oracle.filter_along_axis(vol, 0, k, 0, 15, vol.mean())) < TIGHT_TOL
 
 
+@pytest.mark.parametrize("env", [{"FDN_FUSED_KERNEL": "2"}, {"FDN_R0_RING": "0"}, {"FDN_R0_RING": "1"}, {"FDN_FORCE_STAGED": "1"}])
+def test_kernel_variants_agree_bit_for_bit(fdn, oracle, tmp_path, env):
+    """Every implementation of the chain step (fused with / without the LDS R0 ring, the two-columns-
+    per-lane kernel, the staged per-iteration kernels) must give the oracle's bits on a multi-band
+    image with interior and edge bands."""
+    vol = _vol((10, 70, 300), seed=12)
+    np.save(tmp_path / "v.npy", vol)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import flowdenoising_amd as fd; v = np.load(%r); "
+            "k = fd.get_gaussian_kernel(1.0); np.save(%r, fd.OF_filter(v, [k, None, k], 0, 5))"
+            % (ROOT, str(tmp_path / "v.npy"), str(tmp_path / "o.npy")))
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    k = oracle.get_gaussian_kernel(1.0)
+    want = oracle.OF_filter(vol, [k, None, k], 0, 5, nthreads=8)
+    assert np.array_equal(np.load(tmp_path / "o.npy"), want)
+
+
 # ---- full-size images (BASELINE.json configs[1] and configs[2]) ---------------------------------
 @pytest.mark.parametrize("axis,shape", [(0, (40, 1024, 1024)), (1, (512, 40, 1024)), (2, (512, 1024, 40))])
 def test_full_size_images_spot_parity(fdn, oracle, axis, shape):
