@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--sigma", type=float, default=2.0)
     ap.add_argument("--axes", default="zyx", help="subset of zyx (configs[1] is 'z')")
     ap.add_argument("--amplitude", type=float, default=100.0)
+    ap.add_argument("--levels", type=int, default=0, help="pyramid levels (-l); configs[4] uses 3")
+    ap.add_argument("--winsize", type=int, default=5, help="Farneback window (-w); configs[4] uses 15")
     ap.add_argument("--cpu-targets", type=int, default=0, help="target slices of the CPU sample (0 = one per core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timers", action="store_true", help="skip per-kernel HIP-event timing")
@@ -139,7 +141,7 @@ def main():
     kernel = _lib.gaussian_kernel(a.sigma)
     kernels = [kernel if c in a.axes else None for c in "zyx"]
     naxes = sum(k is not None for k in kernels)
-    params = _lib.SweepParams(0, 5, 3, 5, 1.2, _lib.BORDER_MEAN_PAD, 1, 1)
+    params = _lib.SweepParams(a.levels, a.winsize, 3, 5, 1.2, _lib.BORDER_MEAN_PAD, 1, 1)
 
     h = _lib.Handle(local_rank)
     h.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -199,7 +201,7 @@ def main():
             "value": round(value, 3), "unit": "Mvoxels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{X}x{Y}x{Z} float32, sigma={a.sigma:g} (K={kernel.size}), levels=0, winsize=5, "
+            "config": {"workload": f"{X}x{Y}x{Z} float32, sigma={a.sigma:g} (K={kernel.size}), levels={a.levels}, winsize={a.winsize}, "
                                    f"OF along {a.axes.upper()}, mean-padded borders (BASELINE.json configs[2])",
                        "axes": a.axes, "parallelism": parallelism, "amplitude": a.amplitude},
         }

@@ -33,24 +33,26 @@
 #include "fdn_internal.h"
 #include "fdn_device.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace fdn {
 
 // Whole-wave lane shifts of an f64 on the VALU (DPP wave_shr:1 / wave_shl:1): lane i receives the
-// value of lane i-1 (i+1).  Measured on MI355X (tools/ubench/rates.hip): ~5 cycles per v_mov_dpp per
+// value of lane i-1 (i+1); the lane shifted in from outside the wave reads 0 (bound_ctrl), which only
+// reaches halo lanes whose results are never used.  Measured on MI355X (tools/ubench/rates.hip): ~5 cycles per v_mov_dpp per
 // SIMD against 24 cycles per ds_bpermute_b32 on the one LDS pipe the four SIMDs share.
 static __device__ __forceinline__ double wave_shr1(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 static __device__ __forceinline__ double wave_shl1(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
@@ -80,7 +82,12 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
 
     const int lane = threadIdx.x & 63;
     const int stage = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long gw = blockIdx.x;
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so giving XCD j the
+    // j-th contiguous eighth of the (pair, band) list keeps the bands of a pair -- which share
+    // their 12 halo columns and their rows in time -- behind one L2.  Speed only, never correctness.
+    const long nwg = gridDim.x, q8 = nwg >> 3, rem8 = nwg & 7;
+    const long xcd = blockIdx.x & 7;
+    const long gw = xcd * q8 + (xcd < rem8 ? xcd : rem8) + (blockIdx.x >> 3);   // a bijection on [0, nwg)
     const int b = (int)(gw / nbands);
     const int band = (int)(gw - (long)b * nbands);
     const int xb = band * BW - HALO;            // column of lane 0
@@ -200,74 +207,83 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
     }
 
     // ===== waves 1..3: iteration `stage` =============================================================
-    const int k = stage;
-    float (*Min)[5][64] = Mring[k - 1];
-    // block-uniform: does any lane of this band have a window column outside the image?
-    const bool edge_band = xb < MH || xb + 63 + MH > W - 1;
-    double vs[5];
-#pragma unroll
-    for (int c = 0; c < 5; c++) vs[c] = 0.;
+    // The loop is instantiated per stage and per band kind (K and EDGE are compile-time inside it) so
+    // that a row step of the common interior band is one basic block: the five channels' running-sum
+    // -> DPP -> f64-add chains then interleave instead of running one after the other.
+    const bool edge_band = xb < MH || xb + 63 + MH > W - 1;   // a window column of some lane is outside the image
     const bool owner = lane >= HALO && lane < 64 - HALO && x < W;
     const float* img1 = stack + (size_t)(pb.t0 + b + pb.d) * HW;
     float2* flow_out = flow_out_base ? (float2*)flow_out_base + (size_t)b * HW : nullptr;
     float* acc = acc_base + (size_t)b * HW;
-    const bool need = in_img && lane >= k * MH && lane < 64 - k * MH;   // lanes whose M_k feeds a valid output
 
-    lds_barrier();
-    for (int t = 0; t < T; t++) {
-        const int y = t - k * STEP;
-        if (y >= 0 && y < H) {
-            // final stage: the accumulator does not depend on this step's flow: load it first
-            float acc_old = 0.f;
-            const size_t o = (size_t)y * W + xc;
-            if (k == ITERS) acc_old = acc[o];
-            if (y == 0) { // vsum before row 0: f32(M[0]*(m+2)) + rows 1..m-1 (clamped)
+    auto stage_loop = [&](auto KT, auto ET) __attribute__((always_inline)) {
+        constexpr int K = decltype(KT)::value;
+        constexpr bool EDGE = decltype(ET)::value;
+        float (*Min)[5][64] = Mring[K - 1];
+        const bool need = in_img && lane >= K * MH && lane < 64 - K * MH;   // lanes whose M_K feeds a valid output
+        double vs[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) vs[c] = 0.;
+        lds_barrier();
+        for (int t = 0; t < T; t++) {
+            const int y = t - K * STEP;
+            if (y >= 0 && y < H) {
+                // final stage: the accumulator does not depend on this step's flow: load it first
+                float acc_old = 0.f;
+                const size_t o = (size_t)y * W + xc;
+                if (K == ITERS) acc_old = acc[o];
+                if (y == 0) { // vsum before row 0: f32(M[0]*(m+2)) + rows 1..m-1 (clamped)
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        double v = (double)(Min[0][c][lane] * (float)(MH + 2));
+#pragma unroll
+                        for (int yy = 1; yy < MH; yy++) v += (double)Min[(yy < H - 1 ? yy : H - 1) % RSP][c][lane];
+                        vs[c] = v;
+                    }
+                }
+                const int rn = (y + MH < H - 1 ? y + MH : H - 1) % RSP;
+                const int ro = (y - MH - 1 > 0 ? y - MH - 1 : 0) % RSP;
+                double a[5];
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
-                    double v = (double)(Min[0][c][lane] * (float)(MH + 2));
+                    vs[c] += (double)(Min[rn][c][lane] - Min[ro][c][lane]);
+                    double s = 0;
+                    if (EDGE) {   // windows reach outside the image: read the lane of the clamped column
 #pragma unroll
-                    for (int yy = 1; yy < MH; yy++) v += (double)Min[(yy < H - 1 ? yy : H - 1) % RSP][c][lane];
-                    vs[c] = v;
+                        for (int j = 0; j <= 2 * MH; j++) s += j == MH ? vs[c] : __shfl(vs[c], src[j], 64);
+                    } else {      // same five terms in the same order, by lane shifts
+                        static_assert(MH == 2, "the DPP window is written for a 5-wide box");
+                        const double m1 = wave_shr1(vs[c]), m2 = wave_shr1(m1);
+                        const double p1 = wave_shl1(vs[c]), p2 = wave_shl1(p1);
+                        s += m2; s += m1; s += vs[c]; s += p1; s += p2;
+                    }
+                    a[c] = s;
+                }
+                const float2 f = solve_flow(a, scale);
+                if (K < ITERS) {
+                    const int s = y % RSP;
+                    float r0[5], mm[5];
+#pragma unroll
+                    for (int c = 0; c < 5; c++) r0[c] = R0L ? R0ring[s][c][lane] : R0[c * HW + o];
+                    update_matrices(y, f, r0, need, mm);
+#pragma unroll
+                    for (int c = 0; c < 5; c++) Mring[K < ITERS ? K : 0][s][c][lane] = mm[c];
+                } else {
+                    const float warped = remap_sample(img1, H, W, xc, y, f);
+                    const float acc_new = (float)((double)acc_old + (double)warped * weight);
+                    if (owner) {
+                        if (flow_out) flow_out[o] = f;
+                        acc[o] = acc_new;
+                    }
                 }
             }
-            const int rn = (y + MH < H - 1 ? y + MH : H - 1) % RSP;
-            const int ro = (y - MH - 1 > 0 ? y - MH - 1 : 0) % RSP;
-            double a[5];
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                vs[c] += (double)(Min[rn][c][lane] - Min[ro][c][lane]);
-                double s = 0;
-                if (edge_band) {   // windows reach outside the image: read the lane of the clamped column
-#pragma unroll
-                    for (int j = 0; j <= 2 * MH; j++) s += j == MH ? vs[c] : __shfl(vs[c], src[j], 64);
-                } else {           // same five terms in the same order, by lane shifts
-                    static_assert(MH == 2, "the DPP window is written for a 5-wide box");
-                    const double m1 = wave_shr1(vs[c]), m2 = wave_shr1(m1);
-                    const double p1 = wave_shl1(vs[c]), p2 = wave_shl1(p1);
-                    s += m2; s += m1; s += vs[c]; s += p1; s += p2;
-                }
-                a[c] = s;
-            }
-            const float2 f = solve_flow(a, scale);
-            if (k < ITERS) {
-                const int s = y % RSP;
-                float r0[5], mm[5];
-#pragma unroll
-                for (int c = 0; c < 5; c++) r0[c] = R0L ? R0ring[s][c][lane] : R0[c * HW + o];
-                update_matrices(y, f, r0, need, mm);
-#pragma unroll
-                for (int c = 0; c < 5; c++) Mring[k < ITERS ? k : 0][s][c][lane] = mm[c];
-            } else {
-                const float warped = remap_sample(img1, H, W, xc, y, f);
-                const float acc_new = (float)((double)acc_old + (double)warped * weight);
-                if (owner) {
-                    if (flow_out) flow_out[o] = f;
-                    acc[o] = acc_new;
-                }
-            }
+            lds_barrier();
         }
-        lds_barrier();
-    }
+    };
+    using std::integral_constant;
+    if (stage == 1) { if (edge_band) stage_loop(integral_constant<int, 1>{}, integral_constant<bool, true>{}); else stage_loop(integral_constant<int, 1>{}, integral_constant<bool, false>{}); }
+    else if (stage == 2) { if (edge_band) stage_loop(integral_constant<int, 2>{}, integral_constant<bool, true>{}); else stage_loop(integral_constant<int, 2>{}, integral_constant<bool, false>{}); }
+    else { if (edge_band) stage_loop(integral_constant<int, 3>{}, integral_constant<bool, true>{}); else stage_loop(integral_constant<int, 3>{}, integral_constant<bool, false>{}); }
 }
 
 bool fused_supported(int winsize, int iters, int H, int W)

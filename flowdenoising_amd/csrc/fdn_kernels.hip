@@ -174,8 +174,12 @@ __global__ __launch_bounds__(256) void k_update_flow_scan(const float* __restric
                                                           PairBatch pb, int H, int W, int m, double scale,
                                                           int nbands, int rows_per_seg)
 {
+    // per-wave exchange buffer for the horizontal window (8-byte LDS reads: ~2 cycles each on the LDS
+    // pipe against 2 x 24 for a ds_bpermute pair, and a 15-wide window needs 70 of them per row)
+    __shared__ double xch[4][5][64];
     const int lane = threadIdx.x & 63;
-    const int band = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wv = threadIdx.x >> 6;
+    const int band = blockIdx.x * 4 + wv;
     if (band >= nbands) return;               // whole wave leaves; no block-level sync below
     const int BW = 64 - 2 * m;
     const int x = band * BW - m + lane;
@@ -207,8 +211,16 @@ __global__ __launch_bounds__(256) void k_update_flow_scan(const float* __restric
 #pragma unroll
         for (int c = 0; c < 5; c++) {
             vs[c] += (double)(p1[c * HW] - p0[c * HW]);
+            xch[wv][c][lane] = vs[c];
+        }
+        // only this wave reads what it wrote, and a wave's LDS operations execute in order
+        const int jlo = lane - m < 0 ? 0 : lane - m, jhi = lane + m > 63 ? 63 : lane + m;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
             double s = 0;
-            for (int j = -m; j <= m; j++) s += __shfl(vs[c], clampi(lane + j, 0, 63), 64);
+            for (int j = lane - m; j < jlo; j++) s += xch[wv][c][0];      // clamped lanes left of the wave
+            for (int j = jlo; j <= jhi; j++) s += xch[wv][c][j];
+            for (int j = jhi + 1; j <= lane + m; j++) s += xch[wv][c][63]; // and right of it
             a[c] = s;
         }
         if (owner) {
