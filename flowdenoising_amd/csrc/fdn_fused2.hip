@@ -16,6 +16,7 @@
 //   (the target's R0 rows are re-read from L2 by the two middle stages instead of an LDS ring).
 #include "fdn_internal.h"
 #include "fdn_device.h"
+#include <type_traits>
 
 namespace fdn {
 
@@ -81,7 +82,10 @@ __global__ __launch_bounds__(256) void k_farneback_fused2(const float* __restric
 
     const int lane = threadIdx.x & 63;
     const int stage = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long gw = blockIdx.x;
+    // XCD-aware order (see fdn_fused.hip): XCD j works on the j-th contiguous eighth of the (pair, band) list
+    const long nwg = gridDim.x, q8 = nwg >> 3, rem8 = nwg & 7;
+    const long xcd = blockIdx.x & 7;
+    const long gw = xcd * q8 + (xcd < rem8 ? xcd : rem8) + (blockIdx.x >> 3);
     const int b = (int)(gw / nbands);
     const int band = (int)(gw - (long)b * nbands);
     const int xb = band * BW - HALO;             // column of lane 0's first pixel (even)
@@ -100,9 +104,9 @@ __global__ __launch_bounds__(256) void k_farneback_fused2(const float* __restric
         by1 = y >= H - 5 ? (H - y - 1 < 2 ? 0.14f : 0.4472f) : 1.f;
     };
     // the lane's two values of one plane row
-    auto load2 = [&](const float* plane, int row) __attribute__((always_inline)) -> float2 {
+    auto load2 = [&](auto ET, const float* plane, int row) __attribute__((always_inline)) -> float2 {
         const float* p = plane + (size_t)row * W;
-        if (!edge_band) { float2u v = *(const float2u*)(p + x0); return make_float2(v.a, v.b); }
+        if (!decltype(ET)::value) { float2u v = *(const float2u*)(p + x0); return make_float2(v.a, v.b); }
         return make_float2(p[xc0], p[xc1]);
     };
     // UpdateMatrices of the lane's two pixels of row ys
@@ -131,52 +135,47 @@ __global__ __launch_bounds__(256) void k_farneback_fused2(const float* __restric
 
     const int T = H + ITERS * STEP;
 
+    using std::integral_constant;
     if (stage == 0) {
         // ===== wave 0: stage A ========================================================================
         const float* flow_in = HAS_FIN ? flow_in_base + (size_t)b * HW * 2 : nullptr;
-        auto load_flow2 = [&](int row, float2& f0, float2& f1) __attribute__((always_inline)) {
-            if (!HAS_FIN) { f0 = f1 = make_float2(0.f, 0.f); return; }
-            const float* p = flow_in + (size_t)row * W * 2;
-            if (!edge_band) {
-                float2u a = *(const float2u*)(p + 2 * x0), c = *(const float2u*)(p + 2 * x0 + 2);
+        auto stageA = [&](auto ET) __attribute__((always_inline)) {
+            constexpr bool EDGE = decltype(ET)::value;
+            auto load_flow2 = [&](int row, float2& f0, float2& f1) __attribute__((always_inline)) {
+                if (!HAS_FIN) { f0 = f1 = make_float2(0.f, 0.f); return; }
+                const float* p = flow_in + (size_t)row * W * 2;
+                float2u a = *(const float2u*)(p + 2 * (EDGE ? xc0 : x0)), c = *(const float2u*)(p + 2 * (EDGE ? xc1 : x0 + 1));
                 f0 = make_float2(a.a, a.b); f1 = make_float2(c.a, c.b);
-            } else {
-                float2u a = *(const float2u*)(p + 2 * xc0), c = *(const float2u*)(p + 2 * xc1);
-                f0 = make_float2(a.a, a.b); f1 = make_float2(c.a, c.b);
+            };
+            float2 fN0, fN1, r0N[5];
+            load_flow2(0, fN0, fN1);
+#pragma unroll
+            for (int c = 0; c < 5; c++) r0N[c] = load2(ET, R0 + c * HW, 0);
+            lds_barrier2();
+            for (int t = 0; t < T; t++) {
+                if (t < H) {
+                    const float2 f0 = fN0, f1 = fN1;
+                    float2 r0[5];
+#pragma unroll
+                    for (int c = 0; c < 5; c++) r0[c] = r0N[c];
+                    const int tn = t + 1 < H ? t + 1 : H - 1;
+                    load_flow2(tn, fN0, fN1);
+#pragma unroll
+                    for (int c = 0; c < 5; c++) r0N[c] = load2(ET, R0 + c * HW, tn);
+                    float2 mm[5];
+                    update_matrices2(t, f0, f1, r0, mm);
+                    const int s = t % RSP;
+#pragma unroll
+                    for (int c = 0; c < 5; c++) Mring[0][s][c][lane] = mm[c];
+                }
+                lds_barrier2();
             }
         };
-        float2 fN0, fN1, r0N[5];
-        load_flow2(0, fN0, fN1);
-#pragma unroll
-        for (int c = 0; c < 5; c++) r0N[c] = load2(R0 + c * HW, 0);
-        lds_barrier2();
-        for (int t = 0; t < T; t++) {
-            if (t < H) {
-                const float2 f0 = fN0, f1 = fN1;
-                float2 r0[5];
-#pragma unroll
-                for (int c = 0; c < 5; c++) r0[c] = r0N[c];
-                const int tn = t + 1 < H ? t + 1 : H - 1;
-                load_flow2(tn, fN0, fN1);
-#pragma unroll
-                for (int c = 0; c < 5; c++) r0N[c] = load2(R0 + c * HW, tn);
-                float2 mm[5];
-                update_matrices2(t, f0, f1, r0, mm);
-                const int s = t % RSP;
-#pragma unroll
-                for (int c = 0; c < 5; c++) Mring[0][s][c][lane] = mm[c];
-            }
-            lds_barrier2();
-        }
+        if (edge_band) stageA(integral_constant<bool, true>{}); else stageA(integral_constant<bool, false>{});
         return;
     }
 
-    // ===== waves 1..3: iteration `stage` ==================================================================
-    const int k = stage;
-    float2 (*Min)[5][64] = Mring[k - 1];
-    double vs0[5], vs1[5];
-#pragma unroll
-    for (int c = 0; c < 5; c++) vs0[c] = vs1[c] = 0.;
+    // ===== waves 1..3: iteration `stage` (instantiated per stage and band kind) ===========================
     const bool own_lane = 2 * lane >= HALO && 2 * lane + 1 < 128 - HALO;
     const bool own0 = own_lane && x0 < W, own1 = own_lane && x1 < W;
     const float* img1 = stack + (size_t)(pb.t0 + b + pb.d) * HW;
@@ -193,69 +192,79 @@ __global__ __launch_bounds__(256) void k_farneback_fused2(const float* __restric
         const double a = __shfl(v0, rel >> 1, 64), c = __shfl(v1, rel >> 1, 64);
         return (rel & 1) ? c : a;
     };
-
-    lds_barrier2();
-    for (int t = 0; t < T; t++) {
-        const int y = t - k * STEP;
-        if (y >= 0 && y < H) {
-            float2 acc_old = make_float2(0.f, 0.f);
-            if (k == ITERS) acc_old = load2(acc, y);
-            if (y == 0) { // vsum before row 0: f32(M[0]*(m+2)) + rows 1..m-1 (clamped)
+    auto stage_loop = [&](auto KT, auto ET) __attribute__((always_inline)) {
+        constexpr int K = decltype(KT)::value;
+        constexpr bool EDGE = decltype(ET)::value;
+        float2 (*Min)[5][64] = Mring[K - 1];
+        double vs0[5], vs1[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) vs0[c] = vs1[c] = 0.;
+        lds_barrier2();
+        for (int t = 0; t < T; t++) {
+            const int y = t - K * STEP;
+            if (y >= 0 && y < H) {
+                float2 acc_old = make_float2(0.f, 0.f);
+                if (K == ITERS) acc_old = load2(ET, acc, y);
+                if (y == 0) { // vsum before row 0: f32(M[0]*(m+2)) + rows 1..m-1 (clamped)
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        const float2 m0 = Min[0][c][lane];
+                        double v0 = (double)(m0.x * (float)(MH + 2)), v1 = (double)(m0.y * (float)(MH + 2));
+#pragma unroll
+                        for (int yy = 1; yy < MH; yy++) {
+                            const float2 mr = Min[(yy < H - 1 ? yy : H - 1) % RSP][c][lane];
+                            v0 += (double)mr.x; v1 += (double)mr.y;
+                        }
+                        vs0[c] = v0; vs1[c] = v1;
+                    }
+                }
+                const int rn = (y + MH < H - 1 ? y + MH : H - 1) % RSP;
+                const int ro = (y - MH - 1 > 0 ? y - MH - 1 : 0) % RSP;
+                double a0[5], a1[5];
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
-                    const float2 m0 = Min[0][c][lane];
-                    double v0 = (double)(m0.x * (float)(MH + 2)), v1 = (double)(m0.y * (float)(MH + 2));
+                    const float2 d = Min[rn][c][lane] - Min[ro][c][lane];
+                    vs0[c] += (double)d.x;
+                    vs1[c] += (double)d.y;
+                    double s0 = 0, s1 = 0;
+                    if (EDGE) {
 #pragma unroll
-                    for (int yy = 1; yy < MH; yy++) {
-                        const float2 mr = Min[(yy < H - 1 ? yy : H - 1) % RSP][c][lane];
-                        v0 += (double)mr.x; v1 += (double)mr.y;
+                        for (int j = 0; j <= 2 * MH; j++) {
+                            s0 += column_value(vs0[c], vs1[c], rel0[j]);
+                            s1 += column_value(vs0[c], vs1[c], rel1[j]);
+                        }
+                    } else { // columns 2l-2 .. 2l+3: left lane's pair, own pair, right lane's pair
+                        const double l0 = wave_shr1_2(vs0[c]), l1 = wave_shr1_2(vs1[c]);
+                        const double g0 = wave_shl1_2(vs0[c]), g1 = wave_shl1_2(vs1[c]);
+                        s0 += l0; s0 += l1; s0 += vs0[c]; s0 += vs1[c]; s0 += g0;
+                        s1 += l1; s1 += vs0[c]; s1 += vs1[c]; s1 += g0; s1 += g1;
                     }
-                    vs0[c] = v0; vs1[c] = v1;
+                    a0[c] = s0; a1[c] = s1;
+                }
+                const float2 f0 = solve_flow(a0, scale), f1 = solve_flow(a1, scale);
+                if (K < ITERS) {
+                    float2 r0[5], mm[5];
+#pragma unroll
+                    for (int c = 0; c < 5; c++) r0[c] = load2(ET, R0 + c * HW, y);
+                    update_matrices2(y, f0, f1, r0, mm);
+                    const int s = y % RSP;
+#pragma unroll
+                    for (int c = 0; c < 5; c++) Mring[K < ITERS ? K : 0][s][c][lane] = mm[c];
+                } else {
+                    const float w0 = remap_sample(img1, H, W, xc0, y, f0), w1 = remap_sample(img1, H, W, xc1, y, f1);
+                    const float n0 = (float)((double)acc_old.x + (double)w0 * weight);
+                    const float n1 = (float)((double)acc_old.y + (double)w1 * weight);
+                    const size_t o = (size_t)y * W;
+                    if (own0) { if (flow_out) *(float2u*)(flow_out + 2 * (o + x0)) = float2u{f0.x, f0.y}; acc[o + x0] = n0; }
+                    if (own1) { if (flow_out) *(float2u*)(flow_out + 2 * (o + x1)) = float2u{f1.x, f1.y}; acc[o + x1] = n1; }
                 }
             }
-            const int rn = (y + MH < H - 1 ? y + MH : H - 1) % RSP;
-            const int ro = (y - MH - 1 > 0 ? y - MH - 1 : 0) % RSP;
-            double a0[5], a1[5];
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                const float2 d = Min[rn][c][lane] - Min[ro][c][lane];
-                vs0[c] += (double)d.x;
-                vs1[c] += (double)d.y;
-                double s0 = 0, s1 = 0;
-                if (edge_band) {
-#pragma unroll
-                    for (int j = 0; j <= 2 * MH; j++) {
-                        s0 += column_value(vs0[c], vs1[c], rel0[j]);
-                        s1 += column_value(vs0[c], vs1[c], rel1[j]);
-                    }
-                } else { // columns 2l-2 .. 2l+3: left lane's pair, own pair, right lane's pair
-                    const double l0 = wave_shr1_2(vs0[c]), l1 = wave_shr1_2(vs1[c]);
-                    const double g0 = wave_shl1_2(vs0[c]), g1 = wave_shl1_2(vs1[c]);
-                    s0 += l0; s0 += l1; s0 += vs0[c]; s0 += vs1[c]; s0 += g0;
-                    s1 += l1; s1 += vs0[c]; s1 += vs1[c]; s1 += g0; s1 += g1;
-                }
-                a0[c] = s0; a1[c] = s1;
-            }
-            const float2 f0 = solve_flow(a0, scale), f1 = solve_flow(a1, scale);
-            if (k < ITERS) {
-                float2 r0[5], mm[5];
-#pragma unroll
-                for (int c = 0; c < 5; c++) r0[c] = load2(R0 + c * HW, y);
-                update_matrices2(y, f0, f1, r0, mm);
-                const int s = y % RSP;
-#pragma unroll
-                for (int c = 0; c < 5; c++) Mring[k < ITERS ? k : 0][s][c][lane] = mm[c];
-            } else {
-                const float w0 = remap_sample(img1, H, W, xc0, y, f0), w1 = remap_sample(img1, H, W, xc1, y, f1);
-                const float n0 = (float)((double)acc_old.x + (double)w0 * weight);
-                const float n1 = (float)((double)acc_old.y + (double)w1 * weight);
-                const size_t o = (size_t)y * W;
-                if (own0) { if (flow_out) *(float2u*)(flow_out + 2 * (o + x0)) = float2u{f0.x, f0.y}; acc[o + x0] = n0; }
-                if (own1) { if (flow_out) *(float2u*)(flow_out + 2 * (o + x1)) = float2u{f1.x, f1.y}; acc[o + x1] = n1; }
-            }
+            lds_barrier2();
         }
-        lds_barrier2();
-    }
+    };
+    if (stage == 1) { if (edge_band) stage_loop(integral_constant<int, 1>{}, integral_constant<bool, true>{}); else stage_loop(integral_constant<int, 1>{}, integral_constant<bool, false>{}); }
+    else if (stage == 2) { if (edge_band) stage_loop(integral_constant<int, 2>{}, integral_constant<bool, true>{}); else stage_loop(integral_constant<int, 2>{}, integral_constant<bool, false>{}); }
+    else { if (edge_band) stage_loop(integral_constant<int, 3>{}, integral_constant<bool, true>{}); else stage_loop(integral_constant<int, 3>{}, integral_constant<bool, false>{}); }
 }
 
 void launch_farneback_fused2(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
