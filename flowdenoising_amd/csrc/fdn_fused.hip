@@ -76,9 +76,10 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
     constexpr int BW = 64 - 2 * HALO;
     constexpr int NRP = (ITERS - 1) * STEP + 2 * D + 2;   // window rows [t-2 STEP-D, t+D] + the one being loaded
     constexpr int WC = 64 + 2 * D;
+    constexpr int WCP = WC + 1;                  // odd row pitch: lanes reading different rows spread over the banks
     __shared__ float Mring[ITERS][RSP][5][64];
     __shared__ float R0ring[R0L ? RSP : 1][5][64];
-    __shared__ float win[WIN ? NRP : 1][5][WC];
+    extern __shared__ float win[];               // [NRP][5][WCP] when WIN (dynamic: with the rings it exceeds 64 KB)
 
     const int lane = threadIdx.x & 63;
     const int stage = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -115,24 +116,25 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
     // Bilinear taps for a stage working on row ys.  `need`: lanes whose result is used.  Fast path:
     // every needed lane's 2x2 footprint lies in window rows [ys-D, ys+D] and the window's columns.
     auto gather = [&](int ys, int x1, int y1, bool need, GatherTaps& g) __attribute__((always_inline)) {
+        if (!WIN) { gather_R1(R1, HW, H, W, x1, y1, g); return; }
         const int x1c = clampi(x1, 0, W - 2), y1c = clampi(y1, 0, H - 2);
         int col = x1c - xw0;
         const int dy = y1c - (ys - D);
         const bool inwin = col >= 0 && col <= WC - 2 && dy >= 0 && dy <= 2 * D - 1;
-        if (!WIN || __any(need && !inwin)) {
-            gather_R1(R1, HW, H, W, x1, y1, g);
-            return;
-        }
+        const bool hit = need && inwin, miss = need && !inwin;
         int r0w = y1c;
-        if (!(need && inwin)) { col = lane + D; r0w = clampi(ys, 0, H - 2); }   // lanes nobody reads: stay inside the window
+        if (!hit) { col = lane + D; r0w = clampi(ys, 0, H - 2); }   // lanes not served from LDS: stay inside the window
         const int s0 = r0w % NRP;
         const int s1 = s0 + 1 == NRP ? 0 : s0 + 1;
-        const float* q0 = &win[s0][0][col];
-        const float* q1 = &win[s1][0][col];
+        const float* q0 = win + (size_t)s0 * 5 * WCP + col;
+        const float* q1 = win + (size_t)s1 * 5 * WCP + col;
 #pragma unroll
         for (int c = 0; c < 5; c++) {
-            g.t0[c].a = q0[c * WC]; g.t0[c].b = q0[c * WC + 1];
-            g.t1[c].a = q1[c * WC]; g.t1[c].b = q1[c * WC + 1];
+            g.t0[c].a = q0[c * WCP]; g.t0[c].b = q0[c * WCP + 1];
+            g.t1[c].a = q1[c * WCP]; g.t1[c].b = q1[c * WCP + 1];
+        }
+        if (__any(miss)) {       // a flow of D pixels or more: those lanes (only) go to global memory
+            if (miss) gather_R1(R1, HW, H, W, x1, y1, g);
         }
     };
     auto update_matrices = [&](int ys, float2 f, const float r0[5], bool need, float mm[5]) __attribute__((always_inline)) {
@@ -160,10 +162,10 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
         auto store_window_row = [&](int v, const float w0[5], const float w1[5]) __attribute__((always_inline)) {
             const int s = v % NRP;
 #pragma unroll
-            for (int c = 0; c < 5; c++) win[s][c][lane] = w0[c];
+            for (int c = 0; c < 5; c++) win[((size_t)s * 5 + c) * WCP + lane] = w0[c];
             if (lane < 2 * D) {
 #pragma unroll
-                for (int c = 0; c < 5; c++) win[s][c][64 + lane] = w1[c];
+                for (int c = 0; c < 5; c++) win[((size_t)s * 5 + c) * WCP + 64 + lane] = w1[c];
             }
         };
         if (WIN) {   // rows 0..D before the first step
@@ -296,24 +298,43 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
 {
     if (pb.npairs <= 0) return;
     (void)iters;
-    constexpr int MH = 2, D = 2;
-    constexpr bool WIN = false;   // see the header: the R1 window only pays when flows stay within +-D pixels
+#ifndef FDN_WIN_D
+#define FDN_WIN_D 4
+#endif
+#ifndef FDN_WIN_R0L
+#define FDN_WIN_R0L false
+#endif
+    constexpr int MH = 2, D = FDN_WIN_D;
     const int BW = 64 - 2 * MH * 3;
     int nbands = (W + BW - 1) / BW;
     long blocks = (long)nbands * pb.npairs;
     double scale = 1. / ((double)winsize * winsize);
     dim3 grid((unsigned)blocks);
-    // R0 ring in LDS (35.8 KB, 4 workgroups per CU, fewer L2 requests: faster when the grid fills the
-    // chip several times over) or R0 re-read from L2 by stages 1 and 2 (26.9 KB, 6 workgroups per CU):
-    // a small batch -- e.g. the 64-slice slab of an 8-GPU run, 1280 workgroups -- then runs in one
-    // wave of workgroups instead of one and a quarter.
+    // Variants (ms per launch of 512 targets of 1024 x 1024 on MI355X in brackets):
+    //  * R1 window in LDS, rows/columns +-D around the three gathering stages, no R0 ring: bilinear
+    //    taps come from LDS, where lanes that read different rows cost bank conflicts instead of one
+    //    cache line each (the per-lane ROW scatter of the global gathers was 27 % of the kernel); lanes
+    //    whose flow leaves the window gather from global memory.  D = 4: 50.3 KB, 3 workgroups per CU
+    //    [20.4]; D = 1, 2, 3: [24.6, 23.2, 21.8]; D = 8 (65.8 KB, 2 per CU): [23.0].
+    //  * no window, R0 ring in LDS (35.8 KB, 4 workgroups per CU) [24.6].
+    //  * no window, no R0 ring (26.9 KB, 6 workgroups per CU) [32]: only for small grids -- e.g. the
+    //    64-slice slab of an 8-GPU run, 1280 workgroups -- which then run in one wave of workgroups.
+    const char* ew = getenv("FDN_WINDOW");
+    const bool window = ew ? atoi(ew) != 0 : true;   // also the fastest on small grids (64 targets: 3.46 vs 3.56 ms)
     const char* env = getenv("FDN_R0_RING");
-    const bool r0l = env ? atoi(env) != 0 : blocks > 256 * 6;
-#define FDN_LAUNCH(R0L, FIN)                                                                                   \
-    hipLaunchKernelGGL((k_farneback_fused<MH, D, WIN, R0L, FIN>), grid, dim3(256), 0, st, Rstack, stack, flow_in, \
-                       flow_out, acc, pb, H, W, scale, weight, nbands)
-    if (r0l) { if (flow_in) FDN_LAUNCH(true, true); else FDN_LAUNCH(true, false); }
-    else     { if (flow_in) FDN_LAUNCH(false, true); else FDN_LAUNCH(false, false); }
+    const bool r0l = window || (env ? atoi(env) != 0 : blocks > 256 * 6);
+    constexpr unsigned win_bytes = (2 * (MH + 1) + 2 * D + 2) * 5 * (64 + 2 * D + 1) * sizeof(float);
+#define FDN_LAUNCH(WINF, R0L, FIN)                                                                                    \
+    do {                                                                                                             \
+        auto kern = k_farneback_fused<MH, D, WINF, R0L, FIN>;                                                         \
+        static bool attr_set = false;                                                                                 \
+        if (WINF && !attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, win_bytes); attr_set = true; } \
+        hipLaunchKernelGGL(kern, grid, dim3(256), WINF ? win_bytes : 0u, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, \
+                           scale, weight, nbands);                                                                   \
+    } while (0)
+    if (window) { if (flow_in) FDN_LAUNCH(true, FDN_WIN_R0L, true); else FDN_LAUNCH(true, FDN_WIN_R0L, false); }
+    else if (r0l) { if (flow_in) FDN_LAUNCH(false, true, true); else FDN_LAUNCH(false, true, false); }
+    else { if (flow_in) FDN_LAUNCH(false, false, true); else FDN_LAUNCH(false, false, false); }
 #undef FDN_LAUNCH
 }
 
