@@ -83,10 +83,10 @@ def measured_traffic(name, nvox):
     with open(path) as f:
         t = json.load(f)
     scale = nvox / t["pixels_per_launch"]
-    return round(t["bytes_per_launch_low"] * scale), (
-        f"(FETCH_SIZE + WRITE_SIZE) x 1024 per launch from {os.path.basename(path)}; read side is a lower bound "
-        f"(gfx950 FETCH_SIZE undercounts by up to 2x, uncalibrated for 4/8-B-per-lane loads): true value in "
-        f"[{t['bytes_per_launch_low'] * scale:.3e}, {t['bytes_per_launch_high'] * scale:.3e}] B")
+    return round(t["bytes_per_launch"] * scale), (
+        f"(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, separate rocprofv3 --pmc passes ({os.path.basename(path)}): "
+        f"{t['bytes_per_pixel']:.0f} B per pixel per launch against 300 algorithmic (M and the per-iteration flows never "
+        "leave the chip) and 68 compulsory")
 
 
 def cpu_baseline(vol_t, shape, kernel, mean, n_targets):
