@@ -16,17 +16,17 @@
 //                                  image (1/32-px quantised bilinear), accumulate
 //   One s_barrier per row step: everything a wave reads in step t was written in an earlier step,
 //   everything it writes goes to LDS slots nobody reads in step t (ring depths below).
-//   LDS per workgroup (52 KB -> 3 workgroups = 12 waves per CU):
+//   LDS per workgroup (50.3 KB -> 3 workgroups = 12 waves per CU):
 //     M rings    [3][2MH+3 rows][5 ch][64 lanes]     the matrices never reach HBM
-//     R0 ring    [2MH+3 rows][5][64]                 target expansion rows, loaded once by wave 0
-//     R1 window  [rows t-2(MH+1)-D .. t+D+1][5][64+2D]  neighbour expansion; every stage gathers its
-//                bilinear taps here, so each R1 row is fetched from L2/HBM once per band (a coalesced
-//                row load issued a step ahead) instead of six times by data-dependent gathers that
-//                miss the 32 KB L1.  A flow leaving the window (|d| >= D) makes that wave gather
-//                from global memory for that step.
+//     R1 window  [rows t-2(MH+1)-D .. t+D+1][5][64+2D+1]  (dynamic LDS, D = 4) neighbour expansion:
+//                every stage gathers its bilinear taps here.  The flows of noisy volumes span several
+//                pixels, so lanes of one wave read different ROWS: from global memory that is one
+//                cache line per lane and instruction (27 % of the kernel's time); from LDS it is bank
+//                conflicts.  Wave 0 loads one R1 row per step, a step ahead.  A lane whose flow leaves
+//                the window (|d| >= D) fetches its taps from global memory.
+//     (optional R0 ring [2MH+3 rows][5][64] when no window is used: target expansion rows loaded once)
 //   Splitting the stages over waves keeps each wave's register state small (one running sum set,
-//   no in-register rings), so the dependent chain LDS -> shuffles -> f64 solve -> gather -> matrices
-//   of twelve waves per CU overlaps, where a single wave running all stages was latency-bound.
+//   no in-register rings: 76 VGPRs), where a single wave running all stages was latency-bound.
 //   Each iteration loses MH columns of validity either side: a band yields 64 - 6 MH = 52 output
 //   columns for winsize 5; windows that reach outside the image read the lane of the clamped
 //   column, which is BORDER_REPLICATE of the running sums.
