@@ -63,7 +63,7 @@ static __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int MH, int D, bool WIN, bool R0L, bool HAS_FIN>
+template <int MH, int D, int DX, bool WIN, bool R0L, bool HAS_FIN>
 __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict__ Rstack, const float* __restrict__ stack,
                                                          const float* __restrict__ flow_in_base, float* __restrict__ flow_out_base,
                                                          float* __restrict__ acc_base, PairBatch pb, int H, int W,
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
     constexpr int HALO = MH * ITERS;
     constexpr int BW = 64 - 2 * HALO;
     constexpr int NRP = (ITERS - 1) * STEP + 2 * D + 2;   // window rows [t-2 STEP-D, t+D] + the one being loaded
-    constexpr int WC = 64 + 2 * D;
+    constexpr int WC = 64 + 2 * DX;               // D: window half-height (rows), DX: half-width (columns)
     constexpr int WCP = WC + 1;                  // odd row pitch: lanes reading different rows spread over the banks
     __shared__ float Mring[ITERS][RSP][5][64];
     __shared__ float R0ring[R0L ? RSP : 1][5][64];
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
     const float* R1 = Rstack + (size_t)(pb.t0 + b + pb.d) * 5 * HW;
     const float bxx = border_factor(xc, W);
     const bool xdamp = border_test(xc, W);
-    const int xw0 = xb - D;                      // image column of window column 0
+    const int xw0 = xb - DX;                     // image column of window column 0
 
     // Lanes the horizontal window of this lane reads: the lane that owns column clamp(x+j).
     // (Replica lanes outside the image are never read: a replica's own window is shifted, so
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
         const bool inwin = col >= 0 && col <= WC - 2 && dy >= 0 && dy <= 2 * D - 1;
         const bool hit = need && inwin, miss = need && !inwin;
         int r0w = y1c;
-        if (!hit) { col = lane + D; r0w = clampi(ys, 0, H - 2); }   // lanes not served from LDS: stay inside the window
+        if (!hit) { col = lane + DX; r0w = clampi(ys, 0, H - 2); }   // lanes not served from LDS: stay inside the window
         const int s0 = r0w % NRP;
         const int s1 = s0 + 1 == NRP ? 0 : s0 + 1;
         const float* q0 = win + (size_t)s0 * 5 * WCP + col;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
             const int s = v % NRP;
 #pragma unroll
             for (int c = 0; c < 5; c++) win[((size_t)s * 5 + c) * WCP + lane] = w0[c];
-            if (lane < 2 * D) {
+            if (lane < 2 * DX) {
 #pragma unroll
                 for (int c = 0; c < 5; c++) win[((size_t)s * 5 + c) * WCP + 64 + lane] = w1[c];
             }
@@ -299,12 +299,15 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
     if (pb.npairs <= 0) return;
     (void)iters;
 #ifndef FDN_WIN_D
-#define FDN_WIN_D 4
+#define FDN_WIN_D 5
+#endif
+#ifndef FDN_WIN_DX
+#define FDN_WIN_DX 4
 #endif
 #ifndef FDN_WIN_R0L
 #define FDN_WIN_R0L false
 #endif
-    constexpr int MH = 2, D = FDN_WIN_D;
+    constexpr int MH = 2, D = FDN_WIN_D, DX = FDN_WIN_DX;
     const int BW = 64 - 2 * MH * 3;
     int nbands = (W + BW - 1) / BW;
     long blocks = (long)nbands * pb.npairs;
@@ -314,8 +317,9 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
     //  * R1 window in LDS, rows/columns +-D around the three gathering stages, no R0 ring: bilinear
     //    taps come from LDS, where lanes that read different rows cost bank conflicts instead of one
     //    cache line each (the per-lane ROW scatter of the global gathers was 27 % of the kernel); lanes
-    //    whose flow leaves the window gather from global memory.  D = 4: 50.3 KB, 3 workgroups per CU
-    //    [20.4]; D = 1, 2, 3: [24.6, 23.2, 21.8]; D = 8 (65.8 KB, 2 per CU): [23.0].
+    //    whose flow leaves the window gather from global memory.  Half-height 5 rows, half-width 4
+    //    columns: 53.2 KB, the most that still lets 3 workgroups share a CU's LDS [19.8]; square
+    //    D = 1, 2, 3, 4: [24.6, 23.2, 21.8, 20.4]; 4 x 6 columns [20.6]; D = 8 (65.8 KB, 2 per CU): [23.0].
     //  * no window, R0 ring in LDS (35.8 KB, 4 workgroups per CU) [24.6].
     //  * no window, no R0 ring (26.9 KB, 6 workgroups per CU) [32]: only for small grids -- e.g. the
     //    64-slice slab of an 8-GPU run, 1280 workgroups -- which then run in one wave of workgroups.
@@ -323,10 +327,10 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
     const bool window = ew ? atoi(ew) != 0 : true;   // also the fastest on small grids (64 targets: 3.46 vs 3.56 ms)
     const char* env = getenv("FDN_R0_RING");
     const bool r0l = window || (env ? atoi(env) != 0 : blocks > 256 * 6);
-    constexpr unsigned win_bytes = (2 * (MH + 1) + 2 * D + 2) * 5 * (64 + 2 * D + 1) * sizeof(float);
+    constexpr unsigned win_bytes = (2 * (MH + 1) + 2 * D + 2) * 5 * (64 + 2 * DX + 1) * sizeof(float);
 #define FDN_LAUNCH(WINF, R0L, FIN)                                                                                    \
     do {                                                                                                             \
-        auto kern = k_farneback_fused<MH, D, WINF, R0L, FIN>;                                                         \
+        auto kern = k_farneback_fused<MH, D, DX, WINF, R0L, FIN>;                                                         \
         static bool attr_set = false;                                                                                 \
         if (WINF && !attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, win_bytes); attr_set = true; } \
         hipLaunchKernelGGL(kern, grid, dim3(256), WINF ? win_bytes : 0u, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, \
