@@ -426,9 +426,6 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
     }
     if (pyramid && build_R_pyramid(h, stack, nstack, H, W, lv, pc)) return -1;
     const bool fused = !pyramid && fused_supported(p->winsize, p->iters, H, W) && !getenv("FDN_FORCE_STAGED");
-    // two columns per lane (128-column bands) unless the image is too narrow to fill them
-    const char* fk = getenv("FDN_FUSED_KERNEL");
-    const bool two_col = fk && atoi(fk) == 2;   // opt-in: measured slower than the one-column kernel so far
     // targets per batch, bounded by the workspace limit.  fused: two flow buffers (16 B/px);
     // staged: flow 8 B + two M sets 40 B per pixel
     size_t per_target = HW * (fused ? 16 : pyramid ? 52 : 48);
@@ -466,12 +463,8 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
                     int d = side == 0 ? -(step + 1) : (step + 1); // nearest neighbour first (seq:95,110)
                     bool keep = p->chained && step + 1 < r;       // the next step is seeded with this flow (seq:98)
                     ScopedTimer t(h, FDN_TIMER_FUSED);
-                    if (two_col)
-                        launch_farneback_fused2(R, stack, fin, keep ? fout : nullptr, acc, PairBatch{n, r + c0, d}, H, W,
-                                                p->winsize, kernel[r + d], st);
-                    else
-                        launch_farneback_fused(R, stack, fin, keep ? fout : nullptr, acc, PairBatch{n, r + c0, d}, H, W,
-                                               p->winsize, p->iters, kernel[r + d], st);
+                    launch_farneback_fused(R, stack, fin, keep ? fout : nullptr, acc, PairBatch{n, r + c0, d}, H, W,
+                                           p->winsize, p->iters, kernel[r + d], st);
                     if (keep) { fin = fout; fout = fout == flow ? flowB : flow; }
                 }
                 continue;

@@ -6,8 +6,8 @@
 // Decomposition: one 256-thread workgroup = one band of 64 image columns of one (target,
 // neighbour) pair, marching down the rows; its four waves are the four STAGES of a software
 // pipeline staggered by MH+1 rows, and rows stream from stage to stage through LDS:
-//     wave 0 (A)  row t          : M0 = UpdateMatrices(R0, R1, flow_in); also streams the next R0 /
-//                                  R1 rows from HBM into LDS
+//     wave 0 (A)  row t          : M0 = UpdateMatrices(R0, R1, flow_in); also streams the next
+//                                  R1 row from HBM into the LDS window
 //     wave k=1,2  row t - 3k     : vsum_k += f32(M_{k-1}[y+MH] - M_{k-1}[y-MH-1])  (OpenCV's f32-fed
 //                                  vertical running sum, carried in registers from row 0, hence
 //                                  bit-faithful), box sum across lanes (f64), 2x2 solve -> flow_k,
@@ -15,21 +15,26 @@
 //     wave 3      row t - 9      : same box sum + solve -> final flow; store it, warp the neighbour
 //                                  image (1/32-px quantised bilinear), accumulate
 //   One s_barrier per row step: everything a wave reads in step t was written in an earlier step,
-//   everything it writes goes to LDS slots nobody reads in step t (ring depths below).
-//   LDS per workgroup (50.3 KB -> 3 workgroups = 12 waves per CU):
-//     M rings    [3][2MH+3 rows][5 ch][64 lanes]     the matrices never reach HBM
-//     R1 window  [rows t-2(MH+1)-D .. t+D+1][5][64+2D+1]  (dynamic LDS, D = 4) neighbour expansion:
-//                every stage gathers its bilinear taps here.  The flows of noisy volumes span several
-//                pixels, so lanes of one wave read different ROWS: from global memory that is one
-//                cache line per lane and instruction (27 % of the kernel's time); from LDS it is bank
-//                conflicts.  Wave 0 loads one R1 row per step, a step ahead.  A lane whose flow leaves
-//                the window (|d| >= D) fetches its taps from global memory.
-//     (optional R0 ring [2MH+3 rows][5][64] when no window is used: target expansion rows loaded once)
-//   Splitting the stages over waves keeps each wave's register state small (one running sum set,
-//   no in-register rings: 76 VGPRs), where a single wave running all stages was latency-bound.
+//   everything it writes goes to LDS slots nobody reads in step t.
+//   LDS per workgroup (40.7 KB -> 4 workgroups = 16 waves per CU):
+//     hand-over  [3][2 slots][5 ch][64 lanes]         row r of M_k sits in slot r & 1 for one step; the
+//                consumer takes it over into a six-row delay line in VGPRs (its own column of rows
+//                y-3 .. y+2 is all the running sum needs), so the matrices never reach HBM and cost
+//                7.7 KB of LDS instead of 3 x 7 rows
+//     R1 window  [rows t-2(MH+1)-D .. t+D+1][5][64+2DX+1]  (dynamic LDS, D = 7 rows, DX = 5 columns)
+//                neighbour expansion: every stage gathers its bilinear taps here.  The flows of noisy
+//                volumes span several pixels, so lanes of one wave read different ROWS: from global
+//                memory that is one cache line per lane and instruction (27 % of the kernel's time
+//                before the window); from LDS it is bank conflicts.  Wave 0 loads one R1 row per
+//                step, a step ahead.  A lane whose flow leaves the window fetches its taps from
+//                global memory.
+//   Splitting the stages over waves keeps each wave's register state small (one running sum set and
+//   one delay line: 100 VGPRs), where a single wave running all stages was latency-bound.
 //   Each iteration loses MH columns of validity either side: a band yields 64 - 6 MH = 52 output
 //   columns for winsize 5; windows that reach outside the image read the lane of the clamped
 //   column, which is BORDER_REPLICATE of the running sums.
+//   Measured (MI355X, 512 targets of 1024 x 1024): 18.1 ms per launch, VALU issue 93 % busy
+//   (DESIGN.md 3.2 has the history and the variants that lost).
 #include "fdn_internal.h"
 #include "fdn_device.h"
 #include <stdlib.h>
@@ -63,7 +68,7 @@ static __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int MH, int D, int DX, bool WIN, bool R0L, bool HAS_FIN>
+template <int MH, int D, int DX, int U, bool HAS_FIN>
 __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict__ Rstack, const float* __restrict__ stack,
                                                          const float* __restrict__ flow_in_base, float* __restrict__ flow_out_base,
                                                          float* __restrict__ acc_base, PairBatch pb, int H, int W,
@@ -71,15 +76,15 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
 {
     constexpr int ITERS = 3;
     constexpr int STEP = MH + 1;                 // row stagger between stages
-    constexpr int RSP = 2 * MH + 3;              // ring depth: newest row being written + 2MH+2 readable
+    constexpr int RSD = 2 * MH + 2;              // rows y-MH-1 .. y+MH of M_{K-1} a consumer holds in VGPRs
+    constexpr int NE = U == RSD ? RSD : RSD + U - 1;   // delay-line registers per channel (U == RSD: a ring, no moves)
     constexpr int HALO = MH * ITERS;
     constexpr int BW = 64 - 2 * HALO;
     constexpr int NRP = (ITERS - 1) * STEP + 2 * D + 2;   // window rows [t-2 STEP-D, t+D] + the one being loaded
     constexpr int WC = 64 + 2 * DX;               // D: window half-height (rows), DX: half-width (columns)
     constexpr int WCP = WC + 1;                  // odd row pitch: lanes reading different rows spread over the banks
-    __shared__ float Mring[ITERS][RSP][5][64];
-    __shared__ float R0ring[R0L ? RSP : 1][5][64];
-    extern __shared__ float win[];               // [NRP][5][WCP] when WIN (dynamic: with the rings it exceeds 64 KB)
+    __shared__ float Mx[ITERS][2][5][64];        // hand-over slots: row r of M_k lives in slot r & 1 for one step
+    extern __shared__ float win[];               // [NRP][5][WCP] (dynamic: sized by the launcher)
 
     const int lane = threadIdx.x & 63;
     const int stage = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -114,9 +119,8 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
         by1 = y >= H - 5 ? (H - y - 1 < 2 ? 0.14f : 0.4472f) : 1.f;
     };
     // Bilinear taps for a stage working on row ys.  `need`: lanes whose result is used.  Fast path:
-    // every needed lane's 2x2 footprint lies in window rows [ys-D, ys+D] and the window's columns.
+    // the lane's 2x2 footprint lies in window rows [ys-D, ys+D] and the window's columns.
     auto gather = [&](int ys, int x1, int y1, bool need, GatherTaps& g) __attribute__((always_inline)) {
-        if (!WIN) { gather_R1(R1, HW, H, W, x1, y1, g); return; }
         const int x1c = clampi(x1, 0, W - 2), y1c = clampi(y1, 0, H - 2);
         int col = x1c - xw0;
         const int dy = y1c - (ys - D);
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
             g.t0[c].a = q0[c * WCP]; g.t0[c].b = q0[c * WCP + 1];
             g.t1[c].a = q1[c * WCP]; g.t1[c].b = q1[c * WCP + 1];
         }
-        if (__any(miss)) {       // a flow of D pixels or more: those lanes (only) go to global memory
+        if (__any(miss)) {       // a flow that leaves the window: those lanes (only) go to global memory
             if (miss) gather_R1(R1, HW, H, W, x1, y1, g);
         }
     };
@@ -147,10 +151,10 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
         finish_M(r0, g, H, W, x1, y1, fx, fy, f.x, f.y, bxx, by0, by1, xdamp || border_test(ys, H), mm);
     };
 
-    const int T = H + ITERS * STEP;
+    const int T = H + ITERS * STEP;              // row steps = barriers every wave executes
 
     if (stage == 0) {
-        // ===== wave 0: stage A + the R0 / R1 row streams ==========================================
+        // ===== wave 0: stage A + the R1 window stream ==============================================
         const float2* flow_in = HAS_FIN ? (const float2*)flow_in_base + (size_t)b * HW : nullptr;
         const int wcol0 = clampi(xw0 + lane, 0, W - 1);        // image columns this lane loads into the window
         const int wcol1 = clampi(xw0 + 64 + lane, 0, W - 1);
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
                 for (int c = 0; c < 5; c++) win[((size_t)s * 5 + c) * WCP + 64 + lane] = w1[c];
             }
         };
-        if (WIN) {   // rows 0..D before the first step
+        {   // rows 0..D before the first step
             float w0[5], w1[5];
             for (int v = 0; v <= (D < H - 1 ? D : H - 1); v++) { load_window_row(v, w0, w1); store_window_row(v, w0, w1); }
         }
@@ -191,17 +195,12 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
                 for (int c = 0; c < 5; c++) r0N[c] = R0[c * HW + on];
                 const int vnext = t + D + 1;                 // window row the next step needs
                 float wl0[5], wl1[5];
-                if (WIN) load_window_row(vnext < H ? vnext : H - 1, wl0, wl1);
-                const int s = t % RSP;
-                if (R0L) {
-#pragma unroll
-                    for (int c = 0; c < 5; c++) R0ring[s][c][lane] = r0[c];
-                }
+                load_window_row(vnext < H ? vnext : H - 1, wl0, wl1);
                 float mm[5];
                 update_matrices(t, f, r0, in_img, mm);
 #pragma unroll
-                for (int c = 0; c < 5; c++) Mring[0][s][c][lane] = mm[c];
-                if (WIN && vnext < H) store_window_row(vnext, wl0, wl1);
+                for (int c = 0; c < 5; c++) Mx[0][t & 1][c][lane] = mm[c];
+                if (vnext < H) store_window_row(vnext, wl0, wl1);
             }
             lds_barrier();
         }
@@ -221,65 +220,110 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
     auto stage_loop = [&](auto KT, auto ET) __attribute__((always_inline)) {
         constexpr int K = decltype(KT)::value;
         constexpr bool EDGE = decltype(ET)::value;
-        float (*Min)[5][64] = Mring[K - 1];
+        float (*Min)[5][64] = Mx[K - 1];
         const bool need = in_img && lane >= K * MH && lane < 64 - K * MH;   // lanes whose M_K feeds a valid output
         double vs[5];
-#pragma unroll
-        for (int c = 0; c < 5; c++) vs[c] = 0.;
+        // Delay line: this lane's column of rows y+MH (newest) .. y-MH-1 of M_{K-1}.  The producer wrote
+        // row n = y+MH in the previous step and rewrites that slot two steps later, so it is taken over
+        // now; rows above the image replicate row 0, rows below it row H-1 (OpenCV's clamped row pointers).
+        float e[NE][5];
         lds_barrier();
-        for (int t = 0; t < T; t++) {
+        int t = 0;
+        for (; t < K * STEP - MH; t++) lds_barrier();          // row 0 of M_{K-1} not yet produced
+#pragma unroll
+        for (int c = 0; c < 5; c++) {                          // step K STEP - MH: n = 0
+            const float m = Min[0][c][lane];
+#pragma unroll
+            for (int i = 0; i < NE; i++) e[i][c] = m;
+            vs[c] = 0.;
+        }
+        lds_barrier();
+        t++;
+        // one row step; UT = position inside the unrolled group: the newest row goes to register
+        // P, the row i steps older is at (P + i) [mod RSD for the ring form]
+        auto row_step = [&](auto UT) __attribute__((always_inline)) {
+            constexpr int u = decltype(UT)::value;
+            constexpr int P = U == RSD ? (RSD - u) % RSD : U - 1 - u;
+            auto at = [](int i) constexpr { return U == RSD ? (P + i) % RSD : P + i; };
             const int y = t - K * STEP;
-            if (y >= 0 && y < H) {
-                // final stage: the accumulator does not depend on this step's flow: load it first
-                float acc_old = 0.f;
-                const size_t o = (size_t)y * W + xc;
-                if (K == ITERS) acc_old = acc[o];
-                if (y == 0) { // vsum before row 0: f32(M[0]*(m+2)) + rows 1..m-1 (clamped)
+            const int n = y + MH;
+            if (y < H) {
+                {
+                    const bool fresh = n <= H - 1;
+                    const int sl = fresh ? (n & 1) : 0;
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
-                        double v = (double)(Min[0][c][lane] * (float)(MH + 2));
-#pragma unroll
-                        for (int yy = 1; yy < MH; yy++) v += (double)Min[(yy < H - 1 ? yy : H - 1) % RSP][c][lane];
-                        vs[c] = v;
+                        const float m = Min[sl][c][lane];
+                        e[at(0)][c] = fresh ? m : e[at(1)][c];
                     }
                 }
-                const int rn = (y + MH < H - 1 ? y + MH : H - 1) % RSP;
-                const int ro = (y - MH - 1 > 0 ? y - MH - 1 : 0) % RSP;
-                double a[5];
+                if (y >= 0) {
+                    // final stage: the accumulator does not depend on this step's flow: load it first
+                    float acc_old = 0.f;
+                    const size_t o = (size_t)y * W + xc;
+                    if (K == ITERS) acc_old = acc[o];
+                    if (y == 0) { // vsum before row 0: f32(M[0]*(m+2)) + rows 1..m-1 (clamped)
 #pragma unroll
-                for (int c = 0; c < 5; c++) {
-                    vs[c] += (double)(Min[rn][c][lane] - Min[ro][c][lane]);
-                    double s = 0;
-                    if (EDGE) {   // windows reach outside the image: read the lane of the clamped column
+                        for (int c = 0; c < 5; c++) {
+                            double v = (double)(e[at(MH)][c] * (float)(MH + 2));
 #pragma unroll
-                        for (int j = 0; j <= 2 * MH; j++) s += j == MH ? vs[c] : __shfl(vs[c], src[j], 64);
-                    } else {      // same five terms in the same order, by lane shifts
-                        static_assert(MH == 2, "the DPP window is written for a 5-wide box");
-                        const double m1 = wave_shr1(vs[c]), m2 = wave_shr1(m1);
-                        const double p1 = wave_shl1(vs[c]), p2 = wave_shl1(p1);
-                        s += m2; s += m1; s += vs[c]; s += p1; s += p2;
+                            for (int yy = 1; yy < MH; yy++) v += (double)e[at(MH - yy)][c];
+                            vs[c] = v;
+                        }
                     }
-                    a[c] = s;
-                }
-                const float2 f = solve_flow(a, scale);
-                if (K < ITERS) {
-                    const int s = y % RSP;
-                    float r0[5], mm[5];
+                    double a[5];
 #pragma unroll
-                    for (int c = 0; c < 5; c++) r0[c] = R0L ? R0ring[s][c][lane] : R0[c * HW + o];
-                    update_matrices(y, f, r0, need, mm);
+                    for (int c = 0; c < 5; c++) {
+                        vs[c] += (double)(e[at(0)][c] - e[at(RSD - 1)][c]);
+                        double s = 0;
+                        if (EDGE) {   // windows reach outside the image: read the lane of the clamped column
 #pragma unroll
-                    for (int c = 0; c < 5; c++) Mring[K < ITERS ? K : 0][s][c][lane] = mm[c];
-                } else {
-                    const float warped = remap_sample(img1, H, W, xc, y, f);
-                    const float acc_new = (float)((double)acc_old + (double)warped * weight);
-                    if (owner) {
-                        if (flow_out) flow_out[o] = f;
-                        acc[o] = acc_new;
+                            for (int j = 0; j <= 2 * MH; j++) s += j == MH ? vs[c] : __shfl(vs[c], src[j], 64);
+                        } else {      // same five terms in the same order, by lane shifts
+                            static_assert(MH == 2, "the DPP window is written for a 5-wide box");
+                            const double m1 = wave_shr1(vs[c]), m2 = wave_shr1(m1);
+                            const double p1 = wave_shl1(vs[c]), p2 = wave_shl1(p1);
+                            s += m2; s += m1; s += vs[c]; s += p1; s += p2;
+                        }
+                        a[c] = s;
+                    }
+                    const float2 f = solve_flow(a, scale);
+                    if (K < ITERS) {
+                        float r0[5], mm[5];
+#pragma unroll
+                        for (int c = 0; c < 5; c++) r0[c] = R0[c * HW + o];
+                        update_matrices(y, f, r0, need, mm);
+#pragma unroll
+                        for (int c = 0; c < 5; c++) Mx[K < ITERS ? K : 0][y & 1][c][lane] = mm[c];
+                    } else {
+                        const float warped = remap_sample(img1, H, W, xc, y, f);
+                        const float acc_new = (float)((double)acc_old + (double)warped * weight);
+                        if (owner) {
+                            if (flow_out) flow_out[o] = f;
+                            acc[o] = acc_new;
+                        }
                     }
                 }
             }
             lds_barrier();
+            t++;
+        };
+        using std::integral_constant;
+        while (t < T) {
+            // U row steps with compile-time register positions; the tail group is cut by the t < T tests
+            row_step(integral_constant<int, 0>{});
+            if (U > 1 && t < T) row_step(integral_constant<int, (U > 1 ? 1 : 0)>{});
+            if (U > 2 && t < T) row_step(integral_constant<int, (U > 2 ? 2 : 0)>{});
+            if (U > 3 && t < T) row_step(integral_constant<int, (U > 3 ? 3 : 0)>{});
+            if (U > 4 && t < T) row_step(integral_constant<int, (U > 4 ? 4 : 0)>{});
+            if (U > 5 && t < T) row_step(integral_constant<int, (U > 5 ? 5 : 0)>{});
+            if (U != RSD) {     // move the line up by U registers
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+#pragma unroll
+                    for (int i = RSD - 2; i >= 0; i--) e[i + U][c] = e[i][c];
+                }
+            }
         }
     };
     using std::integral_constant;
@@ -299,47 +343,27 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
     if (pb.npairs <= 0) return;
     (void)iters;
 #ifndef FDN_WIN_D
-#define FDN_WIN_D 5
+#define FDN_WIN_D 7
 #endif
 #ifndef FDN_WIN_DX
-#define FDN_WIN_DX 4
+#define FDN_WIN_DX 5
 #endif
-#ifndef FDN_WIN_R0L
-#define FDN_WIN_R0L false
+#ifndef FDN_UNROLL
+#define FDN_UNROLL 3
 #endif
-    constexpr int MH = 2, D = FDN_WIN_D, DX = FDN_WIN_DX;
+    constexpr int MH = 2, D = FDN_WIN_D, DX = FDN_WIN_DX, U = FDN_UNROLL;
     const int BW = 64 - 2 * MH * 3;
     int nbands = (W + BW - 1) / BW;
     long blocks = (long)nbands * pb.npairs;
     double scale = 1. / ((double)winsize * winsize);
     dim3 grid((unsigned)blocks);
-    // Variants (ms per launch of 512 targets of 1024 x 1024 on MI355X in brackets):
-    //  * R1 window in LDS, rows/columns +-D around the three gathering stages, no R0 ring: bilinear
-    //    taps come from LDS, where lanes that read different rows cost bank conflicts instead of one
-    //    cache line each (the per-lane ROW scatter of the global gathers was 27 % of the kernel); lanes
-    //    whose flow leaves the window gather from global memory.  Half-height 5 rows, half-width 4
-    //    columns: 53.2 KB, the most that still lets 3 workgroups share a CU's LDS [19.8]; square
-    //    D = 1, 2, 3, 4: [24.6, 23.2, 21.8, 20.4]; 4 x 6 columns [20.6]; D = 8 (65.8 KB, 2 per CU): [23.0].
-    //  * no window, R0 ring in LDS (35.8 KB, 4 workgroups per CU) [24.6].
-    //  * no window, no R0 ring (26.9 KB, 6 workgroups per CU) [32]: only for small grids -- e.g. the
-    //    64-slice slab of an 8-GPU run, 1280 workgroups -- which then run in one wave of workgroups.
-    const char* ew = getenv("FDN_WINDOW");
-    const bool window = ew ? atoi(ew) != 0 : true;   // also the fastest on small grids (64 targets: 3.46 vs 3.56 ms)
-    const char* env = getenv("FDN_R0_RING");
-    const bool r0l = window || (env ? atoi(env) != 0 : blocks > 256 * 6);
     constexpr unsigned win_bytes = (2 * (MH + 1) + 2 * D + 2) * 5 * (64 + 2 * DX + 1) * sizeof(float);
-#define FDN_LAUNCH(WINF, R0L, FIN)                                                                                    \
-    do {                                                                                                             \
-        auto kern = k_farneback_fused<MH, D, DX, WINF, R0L, FIN>;                                                         \
-        static bool attr_set = false;                                                                                 \
-        if (WINF && !attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, win_bytes); attr_set = true; } \
-        hipLaunchKernelGGL(kern, grid, dim3(256), WINF ? win_bytes : 0u, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, \
-                           scale, weight, nbands);                                                                   \
-    } while (0)
-    if (window) { if (flow_in) FDN_LAUNCH(true, FDN_WIN_R0L, true); else FDN_LAUNCH(true, FDN_WIN_R0L, false); }
-    else if (r0l) { if (flow_in) FDN_LAUNCH(false, true, true); else FDN_LAUNCH(false, true, false); }
-    else { if (flow_in) FDN_LAUNCH(false, false, true); else FDN_LAUNCH(false, false, false); }
-#undef FDN_LAUNCH
+    static_assert(win_bytes + 3 * 2 * 5 * 64 * sizeof(float) <= 40960, "4 workgroups per CU share 160 KB of LDS");
+    auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, grid, dim3(256), win_bytes, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands);
+    };
+    if (flow_in) launch(k_farneback_fused<MH, D, DX, U, true>);
+    else launch(k_farneback_fused<MH, D, DX, U, false>);
 }
 
 } // namespace fdn

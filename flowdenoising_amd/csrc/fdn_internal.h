@@ -67,11 +67,6 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
                             float* acc, PairBatch pb, int H, int W, int winsize, int iters, double weight,
                             hipStream_t st);
 
-// the same chain step with two image columns per lane (fdn_fused2.hip): 128-column bands, packed f32
-// math; preferred for images at least ~100 pixels wide
-void launch_farneback_fused2(const float* Rstack, const float* stack, const float* flow_in, float* flow_out,
-                             float* acc, PairBatch pb, int H, int W, int winsize, double weight, hipStream_t st);
-
 void launch_fill(float* dst, float value, size_t count, hipStream_t st);
 void launch_permute(const float* in, float* out, int A, int B, int C, int64_t sa, int64_t sb,
                     int64_t sc, hipStream_t st);
