@@ -389,11 +389,50 @@ static int pyramid_batch(fdn_ctx* h, const std::vector<PyrLevel>& lv, const floa
     return 0;
 }
 
-static int ensure_flow_pyramid(fdn_ctx* h, std::vector<PyrLevel>& lv, int n)
+// `copies` flow buffers per level k >= 1 (the fused kernel cannot update a flow in place: the bands of
+// one pair run at their own pace and read each other's halo columns)
+static int ensure_flow_pyramid(fdn_ctx* h, std::vector<PyrLevel>& lv, int n, int copies = 1)
 {
     size_t total = 0;
-    for (size_t k = 1; k < lv.size(); k++) { lv[k].f_off = total; total += (size_t)n * lv[k].h * lv[k].w * 2; }
+    for (size_t k = 1; k < lv.size(); k++) { lv[k].f_off = total; total += (size_t)copies * n * lv[k].h * lv[k].w * 2; }
     return ensure(h, h->flow_pyr, std::max<size_t>(total, 1) * sizeof(float));
+}
+
+// One chain step of a pyramid sweep on the fused kernel: calc()'s levels, coarsest first, each
+// one launch; the finest level also warps the neighbour and accumulates.  `prev` (n x H x W x 2)
+// is the previous step's flow or nullptr; `in0` / return value: the two level-0 flow buffers.
+static int pyramid_step_fused(fdn_ctx* h, const std::vector<PyrLevel>& lv, const float* R0, const float* stack, const float* prev,
+                              float* in0, float* out0, float* acc, PairBatch pb, int H, int W, int winsize, int iters, double weight)
+{
+    const int L = (int)lv.size() - 1;
+    float* fp = (float*)h->flow_pyr.p;
+    const int n = pb.npairs;
+    const float* fin = nullptr;
+    for (int k = L; k >= 1; k--) {
+        const size_t cnt = (size_t)n * lv[k].h * lv[k].w * 2;
+        float* a = fp + lv[k].f_off;
+        float* b = a + cnt;
+        if (k == L) {
+            if (prev) {
+                ScopedTimer t(h, FDN_TIMER_PERMUTE);
+                if (resize_dev(h, prev, H, W, a, lv[L].h, lv[L].w, 2, n, 3, true, lv[L].scale)) return -1;
+                fin = a;
+            }
+        } else {
+            fin = a;     // filled by the resize below in the previous round
+        }
+        {
+            ScopedTimer t(h, FDN_TIMER_FUSED);
+            launch_farneback_fused((const float*)h->Rpyr.p + lv[k].r_off, nullptr, fin, b, nullptr, pb, lv[k].h, lv[k].w,
+                                   winsize, iters, 0.0, h->stream);
+        }
+        float* next_in = k == 1 ? in0 : fp + lv[k - 1].f_off;
+        ScopedTimer t(h, FDN_TIMER_PERMUTE);
+        if (resize_dev(h, b, lv[k].h, lv[k].w, next_in, lv[k - 1].h, lv[k - 1].w, 2, n, 1, true, 2.0)) return -1;
+    }
+    ScopedTimer t(h, FDN_TIMER_FUSED);
+    launch_farneback_fused(R0, stack, in0, out0, acc, pb, H, W, winsize, iters, weight, h->stream);
+    return 0;
 }
 
 static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H, int W, const double* kernel, int K,
@@ -425,10 +464,12 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
         launch_blur3_polyexp(stack, (float*)h->R.p, nstack, H, W, pc, st);
     }
     if (pyramid && build_R_pyramid(h, stack, nstack, H, W, lv, pc)) return -1;
-    const bool fused = !pyramid && fused_supported(p->winsize, p->iters, H, W) && !getenv("FDN_FORCE_STAGED");
-    // targets per batch, bounded by the workspace limit.  fused: two flow buffers (16 B/px);
+    bool fused = fused_supported(p->winsize, p->iters, H, W) && !getenv("FDN_FORCE_STAGED");
+    for (size_t k = 1; k < lv.size(); k++) fused = fused && fused_supported(p->winsize, p->iters, lv[k].h, lv[k].w);
+    // targets per batch, bounded by the workspace limit.  fused: two flow buffers (16 B/px), with a
+    // pyramid two more per coarser level;
     // staged: flow 8 B + two M sets 40 B per pixel
-    size_t per_target = HW * (fused ? 16 : pyramid ? 52 : 48);
+    size_t per_target = HW * (fused ? (pyramid ? 22 : 16) : pyramid ? 52 : 48);
     size_t budget = h->ws_limit;
     if (!budget) {
         size_t fre = 0, tot = 0;
@@ -440,6 +481,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
     float* R = (float*)h->R.p;
     if (fused) {
         if (ensure(h, h->flow, (size_t)C * HW * 16)) return -1;
+        if (pyramid && ensure_flow_pyramid(h, lv, C, 2)) return -1;
     } else {
         if (ensure(h, h->flow, (size_t)C * HW * 8)) return -1;
         if (ensure(h, h->M0, (size_t)C * HW * 20)) return -1;
@@ -462,6 +504,15 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
                 for (int step = 0; step < r; step++) {
                     int d = side == 0 ? -(step + 1) : (step + 1); // nearest neighbour first (seq:95,110)
                     bool keep = p->chained && step + 1 < r;       // the next step is seeded with this flow (seq:98)
+                    if (pyramid) {
+                        // level-0 buffers: `fout` receives this step's flow, the other one the upsampled flow
+                        float* in0 = fout == flow ? flowB : flow;
+                        const float* prev = fin;      // == in0's buffer: consumed by the shrink before in0 is written
+                        if (pyramid_step_fused(h, lv, R, stack, prev, in0, keep ? fout : nullptr, acc, PairBatch{n, r + c0, d}, H, W,
+                                               p->winsize, p->iters, kernel[r + d])) return -1;
+                        if (keep) { fin = fout; fout = in0; }
+                        continue;
+                    }
                     ScopedTimer t(h, FDN_TIMER_FUSED);
                     launch_farneback_fused(R, stack, fin, keep ? fout : nullptr, acc, PairBatch{n, r + c0, d}, H, W,
                                            p->winsize, p->iters, kernel[r + d], st);

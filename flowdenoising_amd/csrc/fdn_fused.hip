@@ -68,7 +68,7 @@ static __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int MH, int D, int DX, int U, bool HAS_FIN>
+template <int MH, int D, int DX, int U, bool HAS_FIN, bool ACC>
 __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict__ Rstack, const float* __restrict__ stack,
                                                          const float* __restrict__ flow_in_base, float* __restrict__ flow_out_base,
                                                          float* __restrict__ acc_base, PairBatch pb, int H, int W,
@@ -213,9 +213,9 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
     // -> DPP -> f64-add chains then interleave instead of running one after the other.
     const bool edge_band = xb < MH || xb + 63 + MH > W - 1;   // a window column of some lane is outside the image
     const bool owner = lane >= HALO && lane < 64 - HALO && x < W;
-    const float* img1 = stack + (size_t)(pb.t0 + b + pb.d) * HW;
+    const float* img1 = ACC ? stack + (size_t)(pb.t0 + b + pb.d) * HW : nullptr;
     float2* flow_out = flow_out_base ? (float2*)flow_out_base + (size_t)b * HW : nullptr;
-    float* acc = acc_base + (size_t)b * HW;
+    float* acc = ACC ? acc_base + (size_t)b * HW : nullptr;
 
     auto stage_loop = [&](auto KT, auto ET) __attribute__((always_inline)) {
         constexpr int K = decltype(KT)::value;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
                     // final stage: the accumulator does not depend on this step's flow: load it first
                     float acc_old = 0.f;
                     const size_t o = (size_t)y * W + xc;
-                    if (K == ITERS) acc_old = acc[o];
+                    if (ACC && K == ITERS) acc_old = acc[o];
                     if (y == 0) { // vsum before row 0: f32(M[0]*(m+2)) + rows 1..m-1 (clamped)
 #pragma unroll
                         for (int c = 0; c < 5; c++) {
@@ -295,13 +295,15 @@ __global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict
                         update_matrices(y, f, r0, need, mm);
 #pragma unroll
                         for (int c = 0; c < 5; c++) Mx[K < ITERS ? K : 0][y & 1][c][lane] = mm[c];
-                    } else {
+                    } else if (ACC) {
                         const float warped = remap_sample(img1, H, W, xc, y, f);
                         const float acc_new = (float)((double)acc_old + (double)warped * weight);
                         if (owner) {
                             if (flow_out) flow_out[o] = f;
                             acc[o] = acc_new;
                         }
+                    } else if (owner) {      // a coarser pyramid level: the flow is the result
+                        flow_out[o] = f;
                     }
                 }
             }
@@ -337,6 +339,7 @@ bool fused_supported(int winsize, int iters, int H, int W)
     return winsize / 2 == 2 && iters == 3 && H >= 2 && W >= 2;
 }
 
+// acc == nullptr: Farneback only (a coarser pyramid level), flow_out is required then.
 void launch_farneback_fused(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
                             PairBatch pb, int H, int W, int winsize, int iters, double weight, hipStream_t st)
 {
@@ -362,8 +365,13 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
     auto launch = [&](auto kern) {
         hipLaunchKernelGGL(kern, grid, dim3(256), win_bytes, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands);
     };
-    if (flow_in) launch(k_farneback_fused<MH, D, DX, U, true>);
-    else launch(k_farneback_fused<MH, D, DX, U, false>);
+    if (acc) {
+        if (flow_in) launch(k_farneback_fused<MH, D, DX, U, true, true>);
+        else launch(k_farneback_fused<MH, D, DX, U, false, true>);
+    } else {
+        if (flow_in) launch(k_farneback_fused<MH, D, DX, U, true, false>);
+        else launch(k_farneback_fused<MH, D, DX, U, false, false>);
+    }
 }
 
 } // namespace fdn

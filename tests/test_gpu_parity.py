@@ -112,6 +112,18 @@ def test_of_filter_with_pyramid(fdn, oracle):
     assert rel_err(got, want) < TIGHT_TOL
 
 
+@pytest.mark.parametrize("shape,l", [((7, 70, 150), 3), ((6, 131, 97), 2), ((5, 64, 200), 1)])
+def test_of_filter_pyramid_on_the_fused_kernel(fdn, oracle, shape, l):
+    """par's default (-l 3 -w 5): every pyramid level of every chain step is one launch of the fused
+    kernel (flow only on the coarser levels), with the INTER_AREA shrink of the previous step's flow
+    and the INTER_LINEAR upsampling between them; odd sizes give non-integer area ratios."""
+    vol = _vol(shape, seed=21)
+    k = fdn.get_gaussian_kernel(1.0)      # K = 9: chains of four steps either side
+    got = fdn.OF_filter_along_Z(vol, k, l, 5, vol.mean())
+    want = oracle.filter_along_axis(vol, 0, k, l, 5, vol.mean(), nthreads=8)
+    assert rel_err(got, want) < TIGHT_TOL
+
+
 def test_get_flow_updates_prev_flow_in_place(fdn):
     rng = np.random.default_rng(4)
     a, b = _img(rng, 40, 40), _img(rng, 40, 40)
