@@ -68,8 +68,8 @@ static __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int MH, int D, int DX, int U, bool HAS_FIN, bool ACC>
-__global__ __launch_bounds__(256) void k_farneback_fused(const float* __restrict__ Rstack, const float* __restrict__ stack,
+template <int MH, int D, int DX, int U, int OCC, bool HAS_FIN, bool ACC>
+__global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __restrict__ Rstack, const float* __restrict__ stack,
                                                          const float* __restrict__ flow_in_base, float* __restrict__ flow_out_base,
                                                          float* __restrict__ acc_base, PairBatch pb, int H, int W,
                                                          double scale, double weight, int nbands)
@@ -339,38 +339,68 @@ bool fused_supported(int winsize, int iters, int H, int W)
     return winsize / 2 == 2 && iters == 3 && H >= 2 && W >= 2;
 }
 
+// One build of the kernel per occupancy: LDS window size, unroll and VGPR budget chosen for OCC
+// workgroups per CU.  (ms per launch of 512 targets of 1024 x 1024 = 10240 workgroups on MI355X.)
+template <int OCC> struct FusedVariant;
+template <> struct FusedVariant<3> { static constexpr int D = 8, DX = 8, U = 3; };   // 46.6 KB [18.9]
+template <> struct FusedVariant<4> { static constexpr int D = 7, DX = 5, U = 3; };   // 40.7 KB [18.1]
+template <> struct FusedVariant<5> { static constexpr int D = 4, DX = 5, U = 1; };   // 31.7 KB, 96 VGPRs
+
+template <int OCC>
+static void launch_variant(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
+                           PairBatch pb, int H, int W, double scale, double weight, int nbands, long blocks, hipStream_t st)
+{
+    constexpr int MH = 2, D = FusedVariant<OCC>::D, DX = FusedVariant<OCC>::DX, U = FusedVariant<OCC>::U;
+    constexpr unsigned win_bytes = (2 * (MH + 1) + 2 * D + 2) * 5 * (64 + 2 * DX + 1) * sizeof(float);
+    // a CU's 160 KB of LDS is handed out in 2 KB granules
+    static_assert(win_bytes + 3 * 2 * 5 * 64 * sizeof(float) <= (160 * 1024 / OCC) / 2048 * 2048, "LDS per workgroup");
+    dim3 grid((unsigned)blocks);
+    auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, grid, dim3(256), win_bytes, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands);
+    };
+    if (acc) {
+        if (flow_in) launch(k_farneback_fused<MH, D, DX, U, OCC, true, true>);
+        else launch(k_farneback_fused<MH, D, DX, U, OCC, false, true>);
+    } else {
+        if (flow_in) launch(k_farneback_fused<MH, D, DX, U, OCC, true, false>);
+        else launch(k_farneback_fused<MH, D, DX, U, OCC, false, false>);
+    }
+}
+
+// Workgroups per CU for a grid of `blocks` workgroups.  All workgroups of a launch take about the same
+// time, so what counts is the number of rounds: large grids run fastest at 4 per CU [18.6 ms for
+// 10240 workgroups against 19.2 at 3 and 19.9 at 5], but a grid that fits one round at 5 and not at 4
+// -- 1280 workgroups: the 64-slice Z slab of an 8-GPU run -- gains 16 % there [2.69 against 3.21 ms].
+// Measured no better: 5 per CU for 2560 workgroups (2 rounds instead of 3), 3 per CU anywhere.
+static int choose_occupancy(long blocks)
+{
+    static int forced = -1, cus = 0;
+    if (forced < 0) {
+        const char* e = getenv("FDN_FUSED_OCC");
+        forced = e ? atoi(e) : 0;
+        hipDeviceProp_t prop;
+        int dev = 0;
+        cus = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+        if (cus <= 0) cus = 256;
+    }
+    if (forced >= 3 && forced <= 5) return forced;
+    return blocks > (long)cus * 4 && blocks <= (long)cus * 5 ? 5 : 4;
+}
+
 // acc == nullptr: Farneback only (a coarser pyramid level), flow_out is required then.
 void launch_farneback_fused(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
                             PairBatch pb, int H, int W, int winsize, int iters, double weight, hipStream_t st)
 {
     if (pb.npairs <= 0) return;
     (void)iters;
-#ifndef FDN_WIN_D
-#define FDN_WIN_D 7
-#endif
-#ifndef FDN_WIN_DX
-#define FDN_WIN_DX 5
-#endif
-#ifndef FDN_UNROLL
-#define FDN_UNROLL 3
-#endif
-    constexpr int MH = 2, D = FDN_WIN_D, DX = FDN_WIN_DX, U = FDN_UNROLL;
-    const int BW = 64 - 2 * MH * 3;
-    int nbands = (W + BW - 1) / BW;
-    long blocks = (long)nbands * pb.npairs;
-    double scale = 1. / ((double)winsize * winsize);
-    dim3 grid((unsigned)blocks);
-    constexpr unsigned win_bytes = (2 * (MH + 1) + 2 * D + 2) * 5 * (64 + 2 * DX + 1) * sizeof(float);
-    static_assert(win_bytes + 3 * 2 * 5 * 64 * sizeof(float) <= 40960, "4 workgroups per CU share 160 KB of LDS");
-    auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, grid, dim3(256), win_bytes, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands);
-    };
-    if (acc) {
-        if (flow_in) launch(k_farneback_fused<MH, D, DX, U, true, true>);
-        else launch(k_farneback_fused<MH, D, DX, U, false, true>);
-    } else {
-        if (flow_in) launch(k_farneback_fused<MH, D, DX, U, true, false>);
-        else launch(k_farneback_fused<MH, D, DX, U, false, false>);
+    const int BW = 64 - 2 * 2 * 3;
+    const int nbands = (W + BW - 1) / BW;
+    const long blocks = (long)nbands * pb.npairs;
+    const double scale = 1. / ((double)winsize * winsize);
+    switch (choose_occupancy(blocks)) {
+    case 3: launch_variant<3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, blocks, st); break;
+    case 5: launch_variant<5>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, blocks, st); break;
+    default: launch_variant<4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, blocks, st); break;
     }
 }
 

@@ -105,11 +105,11 @@ def test_wide_window_uses_the_staged_path(fdn, oracle):
     assert rel_err(got, oracle.filter_along_axis(vol, 0, k, 0, 15, vol.mean())) < TIGHT_TOL
 
 
-@pytest.mark.parametrize("env", [{}, {"FDN_FORCE_STAGED": "1"}])
+@pytest.mark.parametrize("env", [{}, {"FDN_FUSED_OCC": "3"}, {"FDN_FUSED_OCC": "5"}, {"FDN_FORCE_STAGED": "1"}])
 def test_kernel_variants_agree_bit_for_bit(fdn, oracle, tmp_path, env):
-    """Both implementations of the chain step (the fused stage-pipelined kernel and the staged
-    per-iteration kernels) must give the oracle's bits on a multi-band image with interior and
-    edge bands."""
+    """Every implementation of the chain step (the fused stage-pipelined kernel in its builds for 3, 4
+    and 5 workgroups per CU -- different LDS windows and unrolls -- and the staged per-iteration
+    kernels) must give the oracle's bits on a multi-band image with interior and edge bands."""
     vol = _vol((10, 70, 300), seed=12)
     np.save(tmp_path / "v.npy", vol)
     code = ("import sys, numpy as np; sys.path.insert(0, %r); import flowdenoising_amd as fd; v = np.load(%r); "
