@@ -45,7 +45,7 @@ def parse():
     return ap.parse_args()
 
 
-def algorithmic_bytes(timers, shape, K, axes):
+def algorithmic_bytes(timers, shape, K, axes, levels=0):
     """SURVEY.md 8(d) per-unit figures x the units each launch processed.
 
     staged path : FarnebackUpdateFlow_Blur launch = M read 20 B + flow write 8 B per pixel, plus,
@@ -63,10 +63,26 @@ def algorithmic_bytes(timers, shape, K, axes):
     if best is None:
         return None
     name, ms, cnt = best
-    bytes_per_launch = per_px[name] * nvox
+    # with a pyramid a chain step is one launch per level; level k has 4^-k of the pixels
+    bytes_per_launch = per_px[name] * nvox * sum(0.25 ** k for k in range(levels + 1)) / (levels + 1)
     avg_ms = ms / cnt
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
     traffic, traffic_note = measured_traffic(name, nvox)
+    extra = {}
+    if traffic:   # what the DRAM counters saw, and what actually limits the kernel (committed PMC pass)
+        extra["hbm_measured"] = {"GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1),
+                                 "frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                v = json.load(f).get("valu")
+            if v:
+                extra["limiter"] = {"unit": "VALU issue", "utilisation": v["valu_issue_utilisation"], "source": v["source"]}
+        except OSError:
+            pass
+    return {**_roofline_core(name, achieved, traffic, traffic_note, bytes_per_launch, avg_ms, cnt), **extra}
+
+
+def _roofline_core(name, achieved, traffic, traffic_note, bytes_per_launch, avg_ms, cnt):
     return {"bound": "hbm", "kernel": {"fused": "k_farneback_fused", "update_flow": "k_update_flow_scan"}[name],
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
@@ -210,7 +226,7 @@ def main():
         res["whole_path"] = {"algorithmic_GBps": round(per_axis_bytes * naxes * nvox / (dt / a.steps) / 1e9 / world, 1),
                              "frac_of_hbm_peak_per_gpu": round(per_axis_bytes * naxes * nvox / (dt / a.steps) / 1e9 / world / HBM_PEAK_GBS, 4)}
         if timers:
-            res["roofline"] = algorithmic_bytes(timers, shape if world == 1 else (Z // world, Y, X), kernel.size, a.axes)
+            res["roofline"] = algorithmic_bytes(timers, shape if world == 1 else (Z // world, Y, X), kernel.size, a.axes, a.levels)
             res["kernel_ms_per_step"] = {k: round(v[0] / a.steps, 2) for k, v in timers.items() if v[1]}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(vol, shape, kernel, mean, a.cpu_targets)
