@@ -39,18 +39,70 @@ static __device__ __forceinline__ bool border_test(int i, int n) { return (unsig
 
 struct GatherTaps { float2u t0[5], t1[5]; };
 
-// issue the ten 8-byte loads of the bilinear gather (two adjacent taps per row per plane)
+// Global accesses as uniform base + 32-bit per-lane BYTE offset: the compiler then emits the
+// "saddr + voffset" form (global_load v, v_off, s[base]) and no 64-bit per-lane address arithmetic.
+// Needs every plane / image to be smaller than 4 GiB (checked by the launchers' callers).
+// A wave-uniform pointer the optimiser cannot fold into other address arithmetic: keeps one SGPR
+// base per plane instead of re-deriving plane addresses with 64-bit per-lane adds.
+template <typename T> static __device__ __forceinline__ T* uniform_ptr(T* p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
+#define FDN_GLOBAL __attribute__((address_space(1)))     // global memory, stated (uniform_ptr's integer round trip hides it)
+typedef float fdn_v2f __attribute__((ext_vector_type(2)));
+template <typename T> static __device__ __forceinline__ T ld_off(const void* base, unsigned byte_off);
+template <> __device__ __forceinline__ float ld_off<float>(const void* base, unsigned byte_off)
+{
+    return *(const FDN_GLOBAL float*)((const FDN_GLOBAL char*)base + byte_off);
+}
+template <> __device__ __forceinline__ float2 ld_off<float2>(const void* base, unsigned byte_off)
+{
+    const fdn_v2f v = *(const FDN_GLOBAL fdn_v2f*)((const FDN_GLOBAL char*)base + byte_off);
+    return make_float2(v.x, v.y);
+}
+template <> __device__ __forceinline__ float2u ld_off<float2u>(const void* base, unsigned byte_off)   // 4-byte aligned pair
+{
+    typedef fdn_v2f __attribute__((aligned(4))) v2f_a4;
+    const v2f_a4 v = *(const FDN_GLOBAL v2f_a4*)((const FDN_GLOBAL char*)base + byte_off);
+    float2u r; r.a = v.x; r.b = v.y;
+    return r;
+}
+static __device__ __forceinline__ void st_off(void* base, unsigned byte_off, float v)
+{
+    *(FDN_GLOBAL float*)((FDN_GLOBAL char*)base + byte_off) = v;
+}
+static __device__ __forceinline__ void st_off(void* base, unsigned byte_off, float2 v)
+{
+    fdn_v2f w; w.x = v.x; w.y = v.y;
+    *(FDN_GLOBAL fdn_v2f*)((FDN_GLOBAL char*)base + byte_off) = w;
+}
+
+// R1p: the five planes' base pointers (wave-uniform)
+static __device__ __forceinline__ void gather_R1_planes(const float* const R1p[5], int H, int W, int x1, int y1, GatherTaps& g)
+{
+    const unsigned off = ((unsigned)clampi(y1, 0, H - 2) * (unsigned)W + (unsigned)clampi(x1, 0, W - 2)) * 4u;
+    const unsigned off1 = off + (unsigned)W * 4u;
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        g.t0[c] = ld_off<float2u>(R1p[c], off);
+        g.t1[c] = ld_off<float2u>(R1p[c], off1);
+    }
+}
+
 static __device__ __forceinline__ void gather_R1(const float* __restrict__ R1, size_t HW, int H, int W,
                                                  int x1, int y1, GatherTaps& g)
 {
     // uniform plane base (SGPRs) + one 32-bit per-lane element offset: the loads take the
     // saddr + voffset form instead of ten 64-bit per-lane address computations
-    const unsigned off = (unsigned)clampi(y1, 0, H - 2) * (unsigned)W + (unsigned)clampi(x1, 0, W - 2);
+    const unsigned off = ((unsigned)clampi(y1, 0, H - 2) * (unsigned)W + (unsigned)clampi(x1, 0, W - 2)) * 4u;
 #pragma unroll
     for (int c = 0; c < 5; c++) {
         const float* plane = R1 + (size_t)c * HW;
-        g.t0[c] = *(const float2u*)(plane + off);
-        g.t1[c] = *(const float2u*)(plane + off + (unsigned)W);
+        g.t0[c] = ld_off<float2u>(plane, off);
+        g.t1[c] = ld_off<float2u>(plane + W, off);
     }
 }
 
@@ -130,9 +182,9 @@ static __device__ __forceinline__ void remap_issue(const float* __restrict__ src
     int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);
     int xa = clampi(ix, 0, W - 1), xb = clampi(ix + 1, 0, W - 1);
     int ya = clampi(iy, 0, H - 1), yb = clampi(iy + 1, 0, H - 1);
-    const float* ra = src + (size_t)ya * W;
-    const float* rb = src + (size_t)yb * W;
-    r.v0 = ra[xa]; r.v1 = ra[xb]; r.v2 = rb[xa]; r.v3 = rb[xb];
+    const unsigned oa = (unsigned)ya * (unsigned)W, ob = (unsigned)yb * (unsigned)W;
+    r.v0 = ld_off<float>(src, (oa + xa) * 4u); r.v1 = ld_off<float>(src, (oa + xb) * 4u);
+    r.v2 = ld_off<float>(src, (ob + xa) * 4u); r.v3 = ld_off<float>(src, (ob + xb) * 4u);
 }
 
 static __device__ __forceinline__ float remap_finish(const RemapTaps& r)

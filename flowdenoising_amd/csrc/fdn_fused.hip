@@ -103,6 +103,10 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
     const size_t HW = (size_t)H * W;
     const float* R0 = Rstack + (size_t)(pb.t0 + b) * 5 * HW;
     const float* R1 = Rstack + (size_t)(pb.t0 + b + pb.d) * 5 * HW;
+    const float* R0p[5];
+    const float* R1p[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) { R0p[c] = uniform_ptr(R0 + c * HW); R1p[c] = uniform_ptr(R1 + c * HW); }
     const float bxx = border_factor(xc, W);
     const bool xdamp = border_test(xc, W);
     const int xw0 = xb - DX;                     // image column of window column 0
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
             g.t1[c].a = q1[c * WCP]; g.t1[c].b = q1[c * WCP + 1];
         }
         if (__any(miss)) {       // a flow that leaves the window: those lanes (only) go to global memory
-            if (miss) gather_R1(R1, HW, H, W, x1, y1, g);
+            if (miss) gather_R1_planes(R1p, H, W, x1, y1, g);
         }
     };
     auto update_matrices = [&](int ys, float2 f, const float r0[5], bool need, float mm[5]) __attribute__((always_inline)) {
@@ -159,9 +163,9 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
         const int wcol0 = clampi(xw0 + lane, 0, W - 1);        // image columns this lane loads into the window
         const int wcol1 = clampi(xw0 + 64 + lane, 0, W - 1);
         auto load_window_row = [&](int v, float w0[5], float w1[5]) __attribute__((always_inline)) {
-            const float* p = R1 + (size_t)v * W;
+            const unsigned vo = (unsigned)v * (unsigned)W;
 #pragma unroll
-            for (int c = 0; c < 5; c++) { w0[c] = p[c * HW + wcol0]; w1[c] = p[c * HW + wcol1]; }
+            for (int c = 0; c < 5; c++) { w0[c] = ld_off<float>(R1p[c], (vo + wcol0) * 4u); w1[c] = ld_off<float>(R1p[c], (vo + wcol1) * 4u); }
         };
         auto store_window_row = [&](int v, const float w0[5], const float w1[5]) __attribute__((always_inline)) {
             const int s = v % NRP;
@@ -177,10 +181,10 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
             for (int v = 0; v <= (D < H - 1 ? D : H - 1); v++) { load_window_row(v, w0, w1); store_window_row(v, w0, w1); }
         }
         // operands of row 0, then always one row ahead
-        float2 fN = HAS_FIN ? flow_in[xc] : make_float2(0.f, 0.f);
+        float2 fN = HAS_FIN ? ld_off<float2>(flow_in, xc * 8u) : make_float2(0.f, 0.f);
         float r0N[5];
 #pragma unroll
-        for (int c = 0; c < 5; c++) r0N[c] = R0[c * HW + xc];
+        for (int c = 0; c < 5; c++) r0N[c] = ld_off<float>(R0p[c], xc * 4u);
         lds_barrier();
         for (int t = 0; t < T; t++) {
             if (t < H) {
@@ -189,10 +193,10 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
 #pragma unroll
                 for (int c = 0; c < 5; c++) r0[c] = r0N[c];
                 const int tn = t + 1 < H ? t + 1 : H - 1;
-                const size_t on = (size_t)tn * W + xc;
-                fN = HAS_FIN ? flow_in[on] : make_float2(0.f, 0.f);
+                const unsigned on = (unsigned)tn * (unsigned)W + (unsigned)xc;
+                fN = HAS_FIN ? ld_off<float2>(flow_in, on * 8u) : make_float2(0.f, 0.f);
 #pragma unroll
-                for (int c = 0; c < 5; c++) r0N[c] = R0[c * HW + on];
+                for (int c = 0; c < 5; c++) r0N[c] = ld_off<float>(R0p[c], on * 4u);
                 const int vnext = t + D + 1;                 // window row the next step needs
                 float wl0[5], wl1[5];
                 load_window_row(vnext < H ? vnext : H - 1, wl0, wl1);
@@ -260,8 +264,8 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
                 if (y >= 0) {
                     // final stage: the accumulator does not depend on this step's flow: load it first
                     float acc_old = 0.f;
-                    const size_t o = (size_t)y * W + xc;
-                    if (ACC && K == ITERS) acc_old = acc[o];
+                    const unsigned o = (unsigned)y * (unsigned)W + (unsigned)xc;
+                    if (ACC && K == ITERS) acc_old = ld_off<float>(acc, o * 4u);
                     if (y == 0) { // vsum before row 0: f32(M[0]*(m+2)) + rows 1..m-1 (clamped)
 #pragma unroll
                         for (int c = 0; c < 5; c++) {
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
                     if (K < ITERS) {
                         float r0[5], mm[5];
 #pragma unroll
-                        for (int c = 0; c < 5; c++) r0[c] = R0[c * HW + o];
+                        for (int c = 0; c < 5; c++) r0[c] = ld_off<float>(R0p[c], o * 4u);
                         update_matrices(y, f, r0, need, mm);
 #pragma unroll
                         for (int c = 0; c < 5; c++) Mx[K < ITERS ? K : 0][y & 1][c][lane] = mm[c];
@@ -299,11 +303,11 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
                         const float warped = remap_sample(img1, H, W, xc, y, f);
                         const float acc_new = (float)((double)acc_old + (double)warped * weight);
                         if (owner) {
-                            if (flow_out) flow_out[o] = f;
-                            acc[o] = acc_new;
+                            if (flow_out) st_off(flow_out, o * 8u, f);
+                            st_off(acc, o * 4u, acc_new);
                         }
                     } else if (owner) {      // a coarser pyramid level: the flow is the result
-                        flow_out[o] = f;
+                        st_off(flow_out, o * 8u, f);
                     }
                 }
             }
@@ -336,7 +340,8 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
 
 bool fused_supported(int winsize, int iters, int H, int W)
 {
-    return winsize / 2 == 2 && iters == 3 && H >= 2 && W >= 2;
+    // the kernel addresses pixels of one image / flow field by 32-bit byte offsets
+    return winsize / 2 == 2 && iters == 3 && H >= 2 && W >= 2 && (size_t)H * W < ((size_t)1 << 29);
 }
 
 // One build of the kernel per occupancy: LDS window size, unroll and VGPR budget chosen for OCC
