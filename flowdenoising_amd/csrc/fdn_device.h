@@ -83,7 +83,8 @@ static __device__ __forceinline__ void st_off(void* base, unsigned byte_off, flo
 // R1p: the five planes' base pointers (wave-uniform)
 static __device__ __forceinline__ void gather_R1_planes(const float* const R1p[5], int H, int W, int x1, int y1, GatherTaps& g)
 {
-    const unsigned off = ((unsigned)clampi(y1, 0, H - 2) * (unsigned)W + (unsigned)clampi(x1, 0, W - 2)) * 4u;
+    // H, W < 2^24 (fused_supported): the 24-bit multiply is exact and full rate
+    const unsigned off = (__umul24((unsigned)clampi(y1, 0, H - 2), (unsigned)W) + (unsigned)clampi(x1, 0, W - 2)) * 4u;
     const unsigned off1 = off + (unsigned)W * 4u;
 #pragma unroll
     for (int c = 0; c < 5; c++) {
@@ -106,9 +107,9 @@ static __device__ __forceinline__ void gather_R1(const float* __restrict__ R1, s
     }
 }
 
-static __device__ __forceinline__ void flow_target(int x, int y, float dx, float dy, int& x1, int& y1, float& fx, float& fy)
+static __device__ __forceinline__ void flow_target(float xf, float yf, float dx, float dy, int& x1, int& y1, float& fx, float& fy)
 {
-    fx = (float)x + dx; fy = (float)y + dy;
+    fx = xf + dx; fy = yf + dy;
     float flx = floorf(fx), fly = floorf(fy);
     x1 = (int)flx; y1 = (int)fly;
     fx -= flx; fy -= fly;
@@ -116,7 +117,7 @@ static __device__ __forceinline__ void flow_target(int x, int y, float dx, float
 
 static __device__ __forceinline__ void finish_M(const float r0[5], const GatherTaps& g, int H, int W, int x1, int y1,
                                                 float fx, float fy, float dx, float dy, float bxx, float by0, float by1,
-                                                bool damp, float m[5])
+                                                bool damp, float m[5], bool any_damp = true)
 {
     const bool inside = (unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1);
     float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
@@ -135,8 +136,11 @@ static __device__ __forceinline__ void finish_M(const float r0[5], const GatherT
     // ((bx0*bx1)*by0)*by1 as OpenCV, == 1.0f away from the border.  `damp` is OpenCV's own region test
     // ((unsigned)(x-5) >= (unsigned)(W-10) || same for y): for images under 10 pixels it is NOT
     // "within 5 pixels of an edge" (the unsigned difference wraps), and the factors are skipped.
-    float scale = damp ? bxx * by0 * by1 : 1.f;
-    r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    // `any_damp` (wave-uniform; false only when no lane has `damp`): skips the multiplications by 1.0f
+    if (any_damp) {
+        float scale = damp ? bxx * by0 * by1 : 1.f;
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
     m[0] = r4 * r4 + r6 * r6;
     m[1] = (r4 + r5) * r6;
     m[2] = r5 * r5 + r6 * r6;

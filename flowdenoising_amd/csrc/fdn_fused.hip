@@ -127,15 +127,19 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
     auto gather = [&](int ys, int x1, int y1, bool need, GatherTaps& g) __attribute__((always_inline)) {
         const int x1c = clampi(x1, 0, W - 2), y1c = clampi(y1, 0, H - 2);
         int col = x1c - xw0;
-        const int dy = y1c - (ys - D);
-        const bool inwin = col >= 0 && col <= WC - 2 && dy >= 0 && dy <= 2 * D - 1;
+        int dy = y1c - (ys - D);
+        const bool inwin = (unsigned)col <= (unsigned)(WC - 2) && (unsigned)dy <= (unsigned)(2 * D - 1);
         const bool hit = need && inwin, miss = need && !inwin;
-        int r0w = y1c;
-        if (!hit) { col = lane + DX; r0w = clampi(ys, 0, H - 2); }   // lanes not served from LDS: stay inside the window
-        const int s0 = r0w % NRP;
-        const int s1 = s0 + 1 == NRP ? 0 : s0 + 1;
-        const float* q0 = win + (size_t)s0 * 5 * WCP + col;
-        const float* q1 = win + (size_t)s1 * 5 * WCP + col;
+        if (!hit) { col = lane + DX; dy = clampi(ys, 0, H - 2) - (ys - D); }   // lanes not served from LDS: stay inside the window
+        // window slot of row ys - D (wave-uniform, scalar unit) + dy, wrapped once: no per-lane modulo
+        int sb = (ys - D) % NRP;
+        sb = sb < 0 ? sb + NRP : sb;
+        unsigned s0 = (unsigned)(sb + dy);
+        s0 = min(s0, s0 - (unsigned)NRP);
+        unsigned s1 = s0 + 1u;
+        s1 = min(s1, s1 - (unsigned)NRP);
+        const float* q0 = win + __umul24(s0, 5u * WCP) + col;
+        const float* q1 = win + __umul24(s1, 5u * WCP) + col;
 #pragma unroll
         for (int c = 0; c < 5; c++) {
             g.t0[c].a = q0[c * WCP]; g.t0[c].b = q0[c * WCP + 1];
@@ -145,14 +149,18 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
             if (miss) gather_R1_planes(R1p, H, W, x1, y1, g);
         }
     };
+    const float xf = (float)xc;
+    // no lane of this band is within 5 columns of an image edge (then rows 5 .. H-6 need no damping at all)
+    const bool band_nodamp = xb >= 5 && xb + 63 <= W - 6;
     auto update_matrices = [&](int ys, float2 f, const float r0[5], bool need, float mm[5]) __attribute__((always_inline)) {
         int x1, y1; float fx, fy;
-        flow_target(xc, ys, f.x, f.y, x1, y1, fx, fy);
+        flow_target(xf, (float)ys, f.x, f.y, x1, y1, fx, fy);
         GatherTaps g;
         gather(ys, x1, y1, need, g);
         float by0, by1;
         row_factor(ys, by0, by1);
-        finish_M(r0, g, H, W, x1, y1, fx, fy, f.x, f.y, bxx, by0, by1, xdamp || border_test(ys, H), mm);
+        const bool any_damp = !(band_nodamp && ys >= 5 && ys < H - 5);
+        finish_M(r0, g, H, W, x1, y1, fx, fy, f.x, f.y, bxx, by0, by1, xdamp || border_test(ys, H), mm, any_damp);
     };
 
     const int T = H + ITERS * STEP;              // row steps = barriers every wave executes
@@ -279,15 +287,16 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
                         vs[c] += (double)(e[at(0)][c] - e[at(RSD - 1)][c]);
-                        double s = 0;
+                        double s;     // the 2 MH + 1 terms left to right, starting from the first
                         if (EDGE) {   // windows reach outside the image: read the lane of the clamped column
+                            s = __shfl(vs[c], src[0], 64);
 #pragma unroll
-                            for (int j = 0; j <= 2 * MH; j++) s += j == MH ? vs[c] : __shfl(vs[c], src[j], 64);
+                            for (int j = 1; j <= 2 * MH; j++) s += j == MH ? vs[c] : __shfl(vs[c], src[j], 64);
                         } else {      // same five terms in the same order, by lane shifts
                             static_assert(MH == 2, "the DPP window is written for a 5-wide box");
                             const double m1 = wave_shr1(vs[c]), m2 = wave_shr1(m1);
                             const double p1 = wave_shl1(vs[c]), p2 = wave_shl1(p1);
-                            s += m2; s += m1; s += vs[c]; s += p1; s += p2;
+                            s = m2; s += m1; s += vs[c]; s += p1; s += p2;
                         }
                         a[c] = s;
                     }
@@ -341,7 +350,7 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
 bool fused_supported(int winsize, int iters, int H, int W)
 {
     // the kernel addresses pixels of one image / flow field by 32-bit byte offsets
-    return winsize / 2 == 2 && iters == 3 && H >= 2 && W >= 2 && (size_t)H * W < ((size_t)1 << 29);
+    return winsize / 2 == 2 && iters == 3 && H >= 2 && W >= 2 && H < (1 << 24) && W < (1 << 24) && (size_t)H * W < ((size_t)1 << 29);
 }
 
 // One build of the kernel per occupancy: LDS window size, unroll and VGPR budget chosen for OCC

@@ -217,9 +217,10 @@ __global__ __launch_bounds__(256) void k_update_flow_scan(const float* __restric
         const int jlo = lane - m < 0 ? 0 : lane - m, jhi = lane + m > 63 ? 63 : lane + m;
 #pragma unroll
         for (int c = 0; c < 5; c++) {
-            double s = 0;
-            for (int j = lane - m; j < jlo; j++) s += xch[wv][c][0];      // clamped lanes left of the wave
-            for (int j = jlo; j <= jhi; j++) s += xch[wv][c][j];
+            // the 2m+1 terms left to right, starting from the first (not from 0.0: the oracle's order)
+            double s = xch[wv][c][jlo];
+            for (int j = lane - m + 1; j < jlo; j++) s += xch[wv][c][0];  // clamped lanes left of the wave
+            for (int j = (lane - m < jlo ? jlo : jlo + 1); j <= jhi; j++) s += xch[wv][c][j];
             for (int j = jhi + 1; j <= lane + m; j++) s += xch[wv][c][63]; // and right of it
             a[c] = s;
         }

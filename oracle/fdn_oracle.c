@@ -565,9 +565,9 @@ static void update_flow_blur(const float* R0, const float* R1, float* flow, floa
             for (int x = 0; x < W * 5; x++) vs[x] += s1[x] - s0[x];
             for (int x = 0; x < W; x++) {
                 double a[5];
-                for (int c = 0; c < 5; c++) {
-                    double s = 0;
-                    for (int j = -m; j <= m; j++) s += vs[clampi(x + j, 0, W - 1) * 5 + c];
+                for (int c = 0; c < 5; c++) {   /* the 2m+1 terms left to right, starting FROM the first */
+                    double s = vs[clampi(x - m, 0, W - 1) * 5 + c];
+                    for (int j = -m + 1; j <= m; j++) s += vs[clampi(x + j, 0, W - 1) * 5 + c];
                     a[c] = s;
                 }
                 solve_flow(a[0], a[1], a[2], a[3], a[4], scale, fl + x * 2);
