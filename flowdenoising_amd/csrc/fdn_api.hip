@@ -399,39 +399,32 @@ static int ensure_flow_pyramid(fdn_ctx* h, std::vector<PyrLevel>& lv, int n, int
 }
 
 // One chain step of a pyramid sweep on the fused kernel: calc()'s levels, coarsest first, each
-// one launch; the finest level also warps the neighbour and accumulates.  `prev` (n x H x W x 2)
-// is the previous step's flow or nullptr; `in0` / return value: the two level-0 flow buffers.
+// one launch; the finest level also warps the neighbour and accumulates.  Every level but the
+// coarsest reads the next coarser level's flow and upsamples it on the fly (INTER_LINEAR x 2).
+// `prev` (n x H x W x 2) is the previous step's flow or nullptr; out0 receives this step's (or nullptr).
 static int pyramid_step_fused(fdn_ctx* h, const std::vector<PyrLevel>& lv, const float* R0, const float* stack, const float* prev,
-                              float* in0, float* out0, float* acc, PairBatch pb, int H, int W, int winsize, int iters, double weight)
+                              float* out0, float* acc, PairBatch pb, int H, int W, int winsize, int iters, double weight)
 {
     const int L = (int)lv.size() - 1;
     float* fp = (float*)h->flow_pyr.p;
     const int n = pb.npairs;
-    const float* fin = nullptr;
-    for (int k = L; k >= 1; k--) {
-        const size_t cnt = (size_t)n * lv[k].h * lv[k].w * 2;
-        float* a = fp + lv[k].f_off;
-        float* b = a + cnt;
-        if (k == L) {
-            if (prev) {
-                ScopedTimer t(h, FDN_TIMER_PERMUTE);
-                if (resize_dev(h, prev, H, W, a, lv[L].h, lv[L].w, 2, n, 3, true, lv[L].scale)) return -1;
-                fin = a;
-            }
-        } else {
-            fin = a;     // filled by the resize below in the previous round
-        }
-        {
-            ScopedTimer t(h, FDN_TIMER_FUSED);
-            launch_farneback_fused((const float*)h->Rpyr.p + lv[k].r_off, nullptr, fin, b, nullptr, pb, lv[k].h, lv[k].w,
-                                   winsize, iters, 0.0, h->stream);
-        }
-        float* next_in = k == 1 ? in0 : fp + lv[k - 1].f_off;
+    const float* fin = nullptr;      // flow handed to the next launch
+    int ch = 0, cw = 0;              // its size when it is a coarser level's
+    if (prev) {
+        float* a = fp + lv[L].f_off;
         ScopedTimer t(h, FDN_TIMER_PERMUTE);
-        if (resize_dev(h, b, lv[k].h, lv[k].w, next_in, lv[k - 1].h, lv[k - 1].w, 2, n, 1, true, 2.0)) return -1;
+        if (resize_dev(h, prev, H, W, a, lv[L].h, lv[L].w, 2, n, 3, true, lv[L].scale)) return -1;
+        fin = a;
+    }
+    for (int k = L; k >= 1; k--) {
+        float* b = fp + lv[k].f_off + (size_t)n * lv[k].h * lv[k].w * 2;
+        ScopedTimer t(h, FDN_TIMER_FUSED);
+        launch_farneback_fused((const float*)h->Rpyr.p + lv[k].r_off, nullptr, fin, b, nullptr, pb, lv[k].h, lv[k].w,
+                               winsize, iters, 0.0, h->stream, ch, cw);
+        fin = b; ch = lv[k].h; cw = lv[k].w;
     }
     ScopedTimer t(h, FDN_TIMER_FUSED);
-    launch_farneback_fused(R0, stack, in0, out0, acc, pb, H, W, winsize, iters, weight, h->stream);
+    launch_farneback_fused(R0, stack, fin, out0, acc, pb, H, W, winsize, iters, weight, h->stream, ch, cw);
     return 0;
 }
 
@@ -505,12 +498,9 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
                     int d = side == 0 ? -(step + 1) : (step + 1); // nearest neighbour first (seq:95,110)
                     bool keep = p->chained && step + 1 < r;       // the next step is seeded with this flow (seq:98)
                     if (pyramid) {
-                        // level-0 buffers: `fout` receives this step's flow, the other one the upsampled flow
-                        float* in0 = fout == flow ? flowB : flow;
-                        const float* prev = fin;      // == in0's buffer: consumed by the shrink before in0 is written
-                        if (pyramid_step_fused(h, lv, R, stack, prev, in0, keep ? fout : nullptr, acc, PairBatch{n, r + c0, d}, H, W,
+                        if (pyramid_step_fused(h, lv, R, stack, fin, keep ? fout : nullptr, acc, PairBatch{n, r + c0, d}, H, W,
                                                p->winsize, p->iters, kernel[r + d])) return -1;
-                        if (keep) { fin = fout; fout = in0; }
+                        if (keep) { fin = fout; fout = fout == flow ? flowB : flow; }
                         continue;
                     }
                     ScopedTimer t(h, FDN_TIMER_FUSED);

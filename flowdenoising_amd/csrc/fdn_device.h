@@ -170,6 +170,35 @@ static __device__ __forceinline__ float2 solve_flow(const double a[5], double sc
     return f;
 }
 
+// cv::resize INTER_LINEAR of a 2-channel f32 image (HResizeLinear then VResizeLinear, f32
+// coefficients) sampled at one destination pixel, times `ps` in f64: calc()'s upsampling of the flow
+// between pyramid levels.  scale_x = sw / dw, scale_y = sh / dh.
+struct LinearTap { int s0, s1; float a0, a1; };
+static __device__ __forceinline__ LinearTap linear_tap(int d, double scale, int n)
+{
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    float fl = floorf(f);
+    int s = (int)fl;
+    f -= fl;
+    if (s < 0) { f = 0; s = 0; }
+    if (s >= n - 1) { f = 0; s = n - 1; }
+    LinearTap t;
+    t.s0 = s; t.s1 = s + 1 < n ? s + 1 : n - 1; t.a1 = f; t.a0 = 1.f - f;
+    return t;
+}
+static __device__ __forceinline__ float2 resize_linear_flow(const float* __restrict__ src, int sw, const LinearTap& tx, const LinearTap& ty, double ps)
+{
+    const unsigned r0 = (unsigned)ty.s0 * (unsigned)sw, r1 = (unsigned)ty.s1 * (unsigned)sw;
+    const float2 p00 = ld_off<float2>(src, (r0 + tx.s0) * 8u), p01 = ld_off<float2>(src, (r0 + tx.s1) * 8u);
+    const float2 p10 = ld_off<float2>(src, (r1 + tx.s0) * 8u), p11 = ld_off<float2>(src, (r1 + tx.s1) * 8u);
+    float2 v;
+    v.x = (p00.x * tx.a0 + p01.x * tx.a1) * ty.a0 + (p10.x * tx.a0 + p11.x * tx.a1) * ty.a1;
+    v.y = (p00.y * tx.a0 + p01.y * tx.a1) * ty.a0 + (p10.y * tx.a0 + p11.y * tx.a1) * ty.a1;
+    v.x = (float)((double)v.x * ps);
+    v.y = (float)((double)v.y * ps);
+    return v;
+}
+
 // remap in two halves so that a kernel can issue the four tap loads one pipeline step before it
 // combines them: remap_issue computes the quantised position and loads, remap_finish weights.
 struct RemapTaps { float v0, v1, v2, v3; int ax, ay; };

@@ -68,11 +68,11 @@ static __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int MH, int D, int DX, int U, int OCC, bool HAS_FIN, bool ACC>
+template <int MH, int D, int DX, int U, int OCC, int FIN, bool ACC>
 __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __restrict__ Rstack, const float* __restrict__ stack,
                                                          const float* __restrict__ flow_in_base, float* __restrict__ flow_out_base,
                                                          float* __restrict__ acc_base, PairBatch pb, int H, int W,
-                                                         double scale, double weight, int nbands)
+                                                         double scale, double weight, int nbands, FlowSource fs)
 {
     constexpr int ITERS = 3;
     constexpr int STEP = MH + 1;                 // row stagger between stages
@@ -167,7 +167,15 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
 
     if (stage == 0) {
         // ===== wave 0: stage A + the R1 window stream ==============================================
-        const float2* flow_in = HAS_FIN ? (const float2*)flow_in_base + (size_t)b * HW : nullptr;
+        // FIN 0: zero flow; 1: flow_in is this level's flow; 2: flow_in is the next coarser level's
+        // (fs.h x fs.w) result, resized INTER_LINEAR and doubled on the fly (calc()'s upsampling)
+        const float* flow_in = FIN == 1 ? flow_in_base + (size_t)b * HW * 2 : FIN == 2 ? flow_in_base + (size_t)b * fs.h * fs.w * 2 : nullptr;
+        const LinearTap ftx = FIN == 2 ? linear_tap(xc, fs.sx, fs.w) : LinearTap{};
+        auto load_flow = [&](int row) __attribute__((always_inline)) -> float2 {
+            if (FIN == 1) return ld_off<float2>(flow_in, ((unsigned)row * (unsigned)W + (unsigned)xc) * 8u);
+            if (FIN == 2) return resize_linear_flow(flow_in, fs.w, ftx, linear_tap(row, fs.sy, fs.h), 2.0);
+            return make_float2(0.f, 0.f);
+        };
         const int wcol0 = clampi(xw0 + lane, 0, W - 1);        // image columns this lane loads into the window
         const int wcol1 = clampi(xw0 + 64 + lane, 0, W - 1);
         auto load_window_row = [&](int v, float w0[5], float w1[5]) __attribute__((always_inline)) {
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
             for (int v = 0; v <= (D < H - 1 ? D : H - 1); v++) { load_window_row(v, w0, w1); store_window_row(v, w0, w1); }
         }
         // operands of row 0, then always one row ahead
-        float2 fN = HAS_FIN ? ld_off<float2>(flow_in, xc * 8u) : make_float2(0.f, 0.f);
+        float2 fN = load_flow(0);
         float r0N[5];
 #pragma unroll
         for (int c = 0; c < 5; c++) r0N[c] = ld_off<float>(R0p[c], xc * 4u);
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
                 for (int c = 0; c < 5; c++) r0[c] = r0N[c];
                 const int tn = t + 1 < H ? t + 1 : H - 1;
                 const unsigned on = (unsigned)tn * (unsigned)W + (unsigned)xc;
-                fN = HAS_FIN ? ld_off<float2>(flow_in, on * 8u) : make_float2(0.f, 0.f);
+                fN = load_flow(tn);
 #pragma unroll
                 for (int c = 0; c < 5; c++) r0N[c] = ld_off<float>(R0p[c], on * 4u);
                 const int vnext = t + D + 1;                 // window row the next step needs
@@ -362,7 +370,7 @@ template <> struct FusedVariant<5> { static constexpr int D = 4, DX = 5, U = 1; 
 
 template <int OCC>
 static void launch_variant(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
-                           PairBatch pb, int H, int W, double scale, double weight, int nbands, long blocks, hipStream_t st)
+                           PairBatch pb, int H, int W, double scale, double weight, int nbands, long blocks, FlowSource fs, hipStream_t st)
 {
     constexpr int MH = 2, D = FusedVariant<OCC>::D, DX = FusedVariant<OCC>::DX, U = FusedVariant<OCC>::U;
     constexpr unsigned win_bytes = (2 * (MH + 1) + 2 * D + 2) * 5 * (64 + 2 * DX + 1) * sizeof(float);
@@ -370,14 +378,17 @@ static void launch_variant(const float* Rstack, const float* stack, const float*
     static_assert(win_bytes + 3 * 2 * 5 * 64 * sizeof(float) <= (160 * 1024 / OCC) / 2048 * 2048, "LDS per workgroup");
     dim3 grid((unsigned)blocks);
     auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, grid, dim3(256), win_bytes, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands);
+        hipLaunchKernelGGL(kern, grid, dim3(256), win_bytes, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, fs);
     };
+    const int fin = !flow_in ? 0 : fs.h > 0 ? 2 : 1;
     if (acc) {
-        if (flow_in) launch(k_farneback_fused<MH, D, DX, U, OCC, true, true>);
-        else launch(k_farneback_fused<MH, D, DX, U, OCC, false, true>);
+        if (fin == 2) launch(k_farneback_fused<MH, D, DX, U, OCC, 2, true>);
+        else if (fin == 1) launch(k_farneback_fused<MH, D, DX, U, OCC, 1, true>);
+        else launch(k_farneback_fused<MH, D, DX, U, OCC, 0, true>);
     } else {
-        if (flow_in) launch(k_farneback_fused<MH, D, DX, U, OCC, true, false>);
-        else launch(k_farneback_fused<MH, D, DX, U, OCC, false, false>);
+        if (fin == 2) launch(k_farneback_fused<MH, D, DX, U, OCC, 2, false>);
+        else if (fin == 1) launch(k_farneback_fused<MH, D, DX, U, OCC, 1, false>);
+        else launch(k_farneback_fused<MH, D, DX, U, OCC, 0, false>);
     }
 }
 
@@ -402,9 +413,12 @@ static int choose_occupancy(long blocks)
 }
 
 // acc == nullptr: Farneback only (a coarser pyramid level), flow_out is required then.
+// coarse_h, coarse_w > 0: flow_in holds the next coarser level's flow of that size (upsampled in the kernel).
 void launch_farneback_fused(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
-                            PairBatch pb, int H, int W, int winsize, int iters, double weight, hipStream_t st)
+                            PairBatch pb, int H, int W, int winsize, int iters, double weight, hipStream_t st,
+                            int coarse_h, int coarse_w)
 {
+    FlowSource fs{coarse_h, coarse_w, coarse_h > 0 ? (double)coarse_w / W : 1.0, coarse_h > 0 ? (double)coarse_h / H : 1.0};
     if (pb.npairs <= 0) return;
     (void)iters;
     const int BW = 64 - 2 * 2 * 3;
@@ -412,9 +426,9 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
     const long blocks = (long)nbands * pb.npairs;
     const double scale = 1. / ((double)winsize * winsize);
     switch (choose_occupancy(blocks)) {
-    case 3: launch_variant<3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, blocks, st); break;
-    case 5: launch_variant<5>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, blocks, st); break;
-    default: launch_variant<4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, blocks, st); break;
+    case 3: launch_variant<3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, blocks, fs, st); break;
+    case 5: launch_variant<5>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, blocks, fs, st); break;
+    default: launch_variant<4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, blocks, fs, st); break;
     }
 }
 

@@ -65,7 +65,10 @@ void launch_warp(const float* src, const float* flow, float* dst, int H, int W, 
 bool fused_supported(int winsize, int iters, int H, int W);
 void launch_farneback_fused(const float* Rstack, const float* stack, const float* flow_in, float* flow_out,
                             float* acc, PairBatch pb, int H, int W, int winsize, int iters, double weight,
-                            hipStream_t st);
+                            hipStream_t st, int coarse_h = 0, int coarse_w = 0);
+
+// where the fused kernel's initial flow comes from when it is the next coarser pyramid level's result
+struct FlowSource { int h, w; double sx, sy; };   // h == 0: flow_in has the image's own size
 
 void launch_fill(float* dst, float value, size_t count, hipStream_t st);
 void launch_permute(const float* in, float* out, int A, int B, int C, int64_t sa, int64_t sb,
