@@ -377,8 +377,9 @@ static void launch_variant(const float* Rstack, const float* stack, const float*
     // a CU's 160 KB of LDS is handed out in 2 KB granules
     static_assert(win_bytes + 3 * 2 * 5 * 64 * sizeof(float) <= (160 * 1024 / OCC) / 2048 * 2048, "LDS per workgroup");
     dim3 grid((unsigned)blocks);
+    static const unsigned lds_pad = getenv("FDN_LDS_PAD") ? (unsigned)atoi(getenv("FDN_LDS_PAD")) : 0u;   // occupancy experiments
     auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, grid, dim3(256), win_bytes, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, fs);
+        hipLaunchKernelGGL(kern, grid, dim3(256), win_bytes + lds_pad, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, fs);
     };
     const int fin = !flow_in ? 0 : fs.h > 0 ? 2 : 1;
     if (acc) {
