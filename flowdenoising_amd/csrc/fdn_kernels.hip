@@ -240,6 +240,82 @@ __global__ __launch_bounds__(256) void k_update_flow_scan(const float* __restric
     }
 }
 
+// The same kernel with the window half-width known at compile time: the 2M+1 LDS reads of a row
+// become immediate-offset ds_read2_b64 pairs.  Lanes outside [M, 64-M) only feed other lanes'
+// windows (their own results are never stored), so their out-of-range terms need no clamping:
+// the exchange row is padded by M entries either side and they read whatever is there.
+template <int M>
+__global__ __launch_bounds__(256) void k_update_flow_scan_t(const float* __restrict__ Rstack, const float* __restrict__ Min_base,
+                                                            float* __restrict__ Mout_base, float* __restrict__ flow_base,
+                                                            PairBatch pb, int H, int W, double scale,
+                                                            int nbands, int rows_per_seg)
+{
+    __shared__ double xch[4][5][64 + 2 * M];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int band = blockIdx.x * 4 + wv;
+    if (band >= nbands) return;               // whole wave leaves; no block-level sync below
+    constexpr int BW = 64 - 2 * M;
+    const int x = band * BW - M + lane;
+    const int xc = clampi(x, 0, W - 1);
+    const size_t HW = (size_t)H * W;
+    const int b = blockIdx.z;
+    const float* Min = Min_base + (size_t)b * 5 * HW;
+    const int ys = blockIdx.y * rows_per_seg;
+    const int ye = ys + rows_per_seg < H ? ys + rows_per_seg : H;
+
+    double vs[5];
+    vsum_init(Min, HW, H, W, xc, M, vs);
+    for (int y = 0; y < ys; y++) { // replay of the vertical recurrence for rows above the segment
+        const float* p1 = Min + (size_t)(y + M < H - 1 ? y + M : H - 1) * W + xc;
+        const float* p0 = Min + (size_t)(y - M - 1 > 0 ? y - M - 1 : 0) * W + xc;
+#pragma unroll
+        for (int c = 0; c < 5; c++) vs[c] += (double)(p1[c * HW] - p0[c * HW]);
+    }
+    const bool owner = lane >= M && lane < 64 - M && x < W;
+    const float* R0 = Rstack + (size_t)(pb.t0 + b) * 5 * HW;
+    const float* R1 = Rstack + (size_t)(pb.t0 + b + pb.d) * 5 * HW;
+    float2* flow = (float2*)flow_base + (size_t)b * HW;
+    float* Mout = Mout_base ? Mout_base + (size_t)b * 5 * HW : nullptr;
+
+    for (int y = ys; y < ye; y++) {
+        const float* p1 = Min + (size_t)(y + M < H - 1 ? y + M : H - 1) * W + xc;
+        const float* p0 = Min + (size_t)(y - M - 1 > 0 ? y - M - 1 : 0) * W + xc;
+        double a[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            vs[c] += (double)(p1[c * HW] - p0[c * HW]);
+            xch[wv][c][lane + M] = vs[c];
+        }
+        // only this wave reads what it wrote and a wave's LDS operations execute in order; the fences
+        // keep the compiler from moving the reads across the writes (other lanes' addresses)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            double s = xch[wv][c][lane];      // the 2M+1 terms left to right, starting from the first
+#pragma unroll
+            for (int k = 1; k <= 2 * M; k++) s += xch[wv][c][lane + k];
+            a[c] = s;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (owner) {
+            float2 f = solve_flow(a, scale);
+            size_t o = (size_t)y * W + x;
+            flow[o] = f;
+            if (Mout) {
+                float r0[5], mm[5];
+#pragma unroll
+                for (int c = 0; c < 5; c++) r0[c] = R0[c * HW + o];
+                compute_M(r0, R1, HW, H, W, x, y, f.x, f.y, mm);
+#pragma unroll
+                for (int c = 0; c < 5; c++) Mout[c * HW + o] = mm[c];
+            }
+        }
+    }
+}
+
 void launch_update_flow(const float* Rstack, const float* Min, float* Mout, float* flow, PairBatch pb,
                         int H, int W, int winsize, hipStream_t st)
 {
@@ -258,7 +334,10 @@ void launch_update_flow(const float* Rstack, const float* Min, float* Mout, floa
     int rows_per_seg = (H + nseg - 1) / nseg;
     nseg = (H + rows_per_seg - 1) / rows_per_seg;
     dim3 grid((nbands + 3) / 4, nseg, pb.npairs);
-    hipLaunchKernelGGL(k_update_flow_scan, grid, dim3(256), 0, st, Rstack, Min, Mout, flow, pb, H, W, m, scale, nbands, rows_per_seg);
+    if (m == 7)        // winsize 15 (BASELINE configs[4]); other widths take the general kernel
+        hipLaunchKernelGGL(k_update_flow_scan_t<7>, grid, dim3(256), 0, st, Rstack, Min, Mout, flow, pb, H, W, scale, nbands, rows_per_seg);
+    else
+        hipLaunchKernelGGL(k_update_flow_scan, grid, dim3(256), 0, st, Rstack, Min, Mout, flow, pb, H, W, m, scale, nbands, rows_per_seg);
 }
 
 // ---------------------------------------------------------------------------------
