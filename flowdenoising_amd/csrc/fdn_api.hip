@@ -445,6 +445,9 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
         return 0;
     }
     if (H < 2 || W < 2) return fail("optical flow needs images of at least 2x2 pixels, got %dx%d", W, H);
+    // the kernels address the pixels of one image by 32-bit byte offsets (8 bytes per pixel pair plane)
+    if (H >= (1 << 24) || W >= (1 << 24) || (size_t)H * W >= ((size_t)1 << 29))
+        return fail("images of %dx%d pixels are not supported (limit: 2^29 pixels per image)", W, H);
     std::vector<PyrLevel> lv = pyramid_levels(p->levels, H, W);
     const bool pyramid = lv.size() > 1;
 
@@ -740,6 +743,9 @@ FDN_API int fdn_farneback(fdn_handle h, const float* prev, const float* next, fl
     FDN_ENTER(h);
     if (!prev || !next || !flow_io) return fail("NULL image/flow pointer");
     if (H < 2 || W < 2) return fail("optical flow needs images of at least 2x2 pixels, got %dx%d", W, H);
+    // the kernels address the pixels of one image by 32-bit byte offsets (8 bytes per pixel pair plane)
+    if (H >= (1 << 24) || W >= (1 << 24) || (size_t)H * W >= ((size_t)1 << 29))
+        return fail("images of %dx%d pixels are not supported (limit: 2^29 pixels per image)", W, H);
     if (flags & ~FDN_USE_INITIAL_FLOW) return fail("unsupported flags 0x%x (only OPTFLOW_USE_INITIAL_FLOW)", flags);
     fdn_sweep_params p{levels, winsize, iters, poly_n, poly_sigma, 0, 1, 1};
     if (check_params(&p, 1)) return -1;

@@ -6,9 +6,6 @@
 
 namespace fdn {
 
-// two adjacent floats at 4-byte alignment (global_load_dwordx2 needs only dword alignment)
-struct __attribute__((packed, aligned(4))) float2u { float a, b; };
-
 static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 static __device__ __forceinline__ int reflect101(int p, int len)
 {
@@ -18,13 +15,8 @@ static __device__ __forceinline__ int reflect101(int p, int len)
 }
 
 // ---------------------------------------------------------------------------------
-// FarnebackUpdateMatrices for one pixel.  r0[5]: R0 at (x,y); R1: planar neighbour
-// expansion (gathered bilinearly at (x+dx, y+dy), exact f32 weights, no quantisation).
-// Branch-free so that several instances interleave in one basic block: the gather always
-// runs at a clamped position and the out-of-image case is a select; the 5-pixel border
-// damping is always multiplied in (it is exactly 1.0f in the interior).  Values are
-// bit-identical to the branching CPU form.  Needs H >= 2 and W >= 2.
-//   bxx = border[x]-factor product for this column, ((x<5 ? b[x] : 1) * (x>=W-5 ? b[W-1-x] : 1))
+// FarnebackUpdateMatrices' 5-pixel border damping.
+//   border_factor: border[x]-factor product for one coordinate, ((x<5 ? b[x] : 1) * (x>=W-5 ? b[W-1-x] : 1))
 // ---------------------------------------------------------------------------------
 static __device__ __forceinline__ float border_factor(int i, int n)
 {
@@ -36,8 +28,6 @@ static __device__ __forceinline__ float border_factor(int i, int n)
 
 // OpenCV's "(unsigned)(i - BORDER) >= (unsigned)(n - BORDER*2)"
 static __device__ __forceinline__ bool border_test(int i, int n) { return (unsigned)(i - 5) >= (unsigned)(n - 10); }
-
-struct GatherTaps { float2u t0[5], t1[5]; };
 
 // Global accesses as uniform base + 32-bit per-lane BYTE offset: the compiler then emits the
 // "saddr + voffset" form (global_load v, v_off, s[base]) and no 64-bit per-lane address arithmetic.
@@ -63,12 +53,21 @@ template <> __device__ __forceinline__ float2 ld_off<float2>(const void* base, u
     const fdn_v2f v = *(const FDN_GLOBAL fdn_v2f*)((const FDN_GLOBAL char*)base + byte_off);
     return make_float2(v.x, v.y);
 }
-template <> __device__ __forceinline__ float2u ld_off<float2u>(const void* base, unsigned byte_off)   // 4-byte aligned pair
+typedef float fdn_v4f __attribute__((ext_vector_type(4)));
+template <> __device__ __forceinline__ fdn_v2f ld_off<fdn_v2f>(const void* base, unsigned byte_off)
 {
-    typedef fdn_v2f __attribute__((aligned(4))) v2f_a4;
-    const v2f_a4 v = *(const FDN_GLOBAL v2f_a4*)((const FDN_GLOBAL char*)base + byte_off);
-    float2u r; r.a = v.x; r.b = v.y;
-    return r;
+    return *(const FDN_GLOBAL fdn_v2f*)((const FDN_GLOBAL char*)base + byte_off);
+}
+// 16 bytes at an 8-byte aligned address / 8 bytes at a 4-byte aligned one (two adjacent pixels)
+static __device__ __forceinline__ fdn_v4f ld_off_v4a8(const void* base, unsigned byte_off)
+{
+    typedef fdn_v4f __attribute__((aligned(8))) v4_a8;
+    return *(const FDN_GLOBAL v4_a8*)((const FDN_GLOBAL char*)base + byte_off);
+}
+static __device__ __forceinline__ fdn_v2f ld_off_v2a4(const void* base, unsigned byte_off)
+{
+    typedef fdn_v2f __attribute__((aligned(4))) v2_a4;
+    return *(const FDN_GLOBAL v2_a4*)((const FDN_GLOBAL char*)base + byte_off);
 }
 static __device__ __forceinline__ void st_off(void* base, unsigned byte_off, float v)
 {
@@ -80,31 +79,48 @@ static __device__ __forceinline__ void st_off(void* base, unsigned byte_off, flo
     *(FDN_GLOBAL fdn_v2f*)((FDN_GLOBAL char*)base + byte_off) = w;
 }
 
-// R1p: the five planes' base pointers (wave-uniform)
-static __device__ __forceinline__ void gather_R1_planes(const float* const R1p[5], int H, int W, int x1, int y1, GatherTaps& g)
+// ---------------------------------------------------------------------------------
+// Layout of a polynomial expansion R in HBM (one image): the five channels as two interleaved
+// pairs and one plane,
+//     [ (c0, c1) x HW ][ (c2, c3) x HW ][ c4 x HW ]          (20 bytes per pixel, as planar)
+// so that a pixel's pair arrives in the two halves of a 64-bit register with one load and the
+// packed f32 instructions (v_pk_mul/add_f32) work on two channels at a time without shuffling.
+// Pixels are addressed by 32-bit byte offsets: H * W < 2^29 (checked on the host).
+// ---------------------------------------------------------------------------------
+struct RImage { const float* p01; const float* p23; const float* p4; };
+static __device__ __forceinline__ RImage r_image(const float* base, size_t HW)
 {
-    // H, W < 2^24 (fused_supported): the 24-bit multiply is exact and full rate
-    const unsigned off = (__umul24((unsigned)clampi(y1, 0, H - 2), (unsigned)W) + (unsigned)clampi(x1, 0, W - 2)) * 4u;
-    const unsigned off1 = off + (unsigned)W * 4u;
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        g.t0[c] = ld_off<float2u>(R1p[c], off);
-        g.t1[c] = ld_off<float2u>(R1p[c], off1);
-    }
+    RImage r; r.p01 = base; r.p23 = base + 2 * HW; r.p4 = base + 4 * HW;
+    return r;
+}
+static __device__ __forceinline__ void load_R(const RImage& R, unsigned px, fdn_v2f& r01, fdn_v2f& r23, float& r4)
+{
+    r01 = ld_off<fdn_v2f>(R.p01, px * 8u);
+    r23 = ld_off<fdn_v2f>(R.p23, px * 8u);
+    r4 = ld_off<float>(R.p4, px * 4u);
 }
 
-static __device__ __forceinline__ void gather_R1(const float* __restrict__ R1, size_t HW, int H, int W,
-                                                 int x1, int y1, GatherTaps& g)
+// The 2 x 2 bilinear footprint of all five channels: [pair]: taps (x1, y1), (x1+1, y1), (x1, y1+1),
+// (x1+1, y1+1) of channels (2 pair, 2 pair + 1); ...s: channel 4.
+struct GatherTapsP {
+    fdn_v2f a0[2], b0[2], a1[2], b1[2];
+    float a0s, b0s, a1s, b1s;
+};
+
+// FarnebackUpdateMatrices' gather at the clamped position (the out-of-image case is a select in
+// finish_M_p): two 16-byte and one 8-byte load per row.  Needs H >= 2, W >= 2, H, W < 2^24.
+static __device__ __forceinline__ void gather_R1_p(const RImage& R1, int H, int W, int x1, int y1, GatherTapsP& g)
 {
-    // uniform plane base (SGPRs) + one 32-bit per-lane element offset: the loads take the
-    // saddr + voffset form instead of ten 64-bit per-lane address computations
-    const unsigned off = ((unsigned)clampi(y1, 0, H - 2) * (unsigned)W + (unsigned)clampi(x1, 0, W - 2)) * 4u;
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        const float* plane = R1 + (size_t)c * HW;
-        g.t0[c] = ld_off<float2u>(plane, off);
-        g.t1[c] = ld_off<float2u>(plane + W, off);
-    }
+    const unsigned px = __umul24((unsigned)clampi(y1, 0, H - 2), (unsigned)W) + (unsigned)clampi(x1, 0, W - 2);
+    const unsigned px1 = px + (unsigned)W;
+    fdn_v4f t;
+    t = ld_off_v4a8(R1.p01, px * 8u);  g.a0[0] = t.xy; g.b0[0] = t.zw;
+    t = ld_off_v4a8(R1.p23, px * 8u);  g.a0[1] = t.xy; g.b0[1] = t.zw;
+    t = ld_off_v4a8(R1.p01, px1 * 8u); g.a1[0] = t.xy; g.b1[0] = t.zw;
+    t = ld_off_v4a8(R1.p23, px1 * 8u); g.a1[1] = t.xy; g.b1[1] = t.zw;
+    fdn_v2f u;
+    u = ld_off_v2a4(R1.p4, px * 4u);  g.a0s = u.x; g.b0s = u.y;
+    u = ld_off_v2a4(R1.p4, px1 * 4u); g.a1s = u.x; g.b1s = u.y;
 }
 
 static __device__ __forceinline__ void flow_target(float xf, float yf, float dx, float dy, int& x1, int& y1, float& fx, float& fy)
@@ -115,49 +131,58 @@ static __device__ __forceinline__ void flow_target(float xf, float yf, float dx,
     fx -= flx; fy -= fly;
 }
 
-static __device__ __forceinline__ void finish_M(const float r0[5], const GatherTaps& g, int H, int W, int x1, int y1,
-                                                float fx, float fy, float dx, float dy, float bxx, float by0, float by1,
-                                                bool damp, float m[5], bool any_damp = true)
+// FarnebackUpdateMatrices for one pixel from its operands: (r01, r23, r4c) = R0 at the pixel, g = the
+// neighbour expansion's 2 x 2 footprint at (x1, y1) = floor(p + flow), (fx, fy) the fractions (exact f32
+// weights, no quantisation), (dx, dy) the flow.  The gather ran at a clamped position; the
+// out-of-image case is a select here.  `any_damp` (wave-uniform; false only when no lane has `damp`)
+// skips the multiplications by the border factor where it is 1.0f.  Channel pairs stay packed
+// (v_pk_* f32); element-wise the operations and their order are those of OpenCV's scalar loop, so the
+// values are bit-identical to the CPU form.  Result: M as (m0, m2), m1, (m3, m4).
+static __device__ __forceinline__ void finish_M_p(fdn_v2f r01, fdn_v2f r23, float r4c, const GatherTapsP& g, int H, int W, int x1, int y1,
+                                                  float fx, float fy, float dx, float dy, float bxx, float by0, float by1,
+                                                  bool damp, bool any_damp, fdn_v2f& m02, float& m1, fdn_v2f& m34)
 {
     const bool inside = (unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1);
-    float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-    float s[5];
-#pragma unroll
-    for (int c = 0; c < 5; c++) s[c] = a00 * g.t0[c].a + a01 * g.t0[c].b + a10 * g.t1[c].a + a11 * g.t1[c].b;
-    float r2 = inside ? s[0] : 0.f;
-    float r3 = inside ? s[1] : 0.f;
-    float r4 = inside ? (r0[2] + s[2]) * 0.5f : r0[2];
-    float r5 = inside ? (r0[3] + s[3]) * 0.5f : r0[3];
-    float r6 = inside ? (r0[4] + s[4]) * 0.25f : r0[4] * 0.5f;
-    r2 = (r0[0] - r2) * 0.5f;
-    r3 = (r0[1] - r3) * 0.5f;
-    r2 = r2 + (r4 * dy + r6 * dx);
-    r3 = r3 + (r6 * dy + r5 * dx);
-    // ((bx0*bx1)*by0)*by1 as OpenCV, == 1.0f away from the border.  `damp` is OpenCV's own region test
-    // ((unsigned)(x-5) >= (unsigned)(W-10) || same for y): for images under 10 pixels it is NOT
-    // "within 5 pixels of an edge" (the unsigned difference wraps), and the factors are skipped.
-    // `any_damp` (wave-uniform; false only when no lane has `damp`): skips the multiplications by 1.0f
+    const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+    const fdn_v2f s01 = a00 * g.a0[0] + a01 * g.b0[0] + a10 * g.a1[0] + a11 * g.b1[0];
+    const fdn_v2f s23 = a00 * g.a0[1] + a01 * g.b0[1] + a10 * g.a1[1] + a11 * g.b1[1];
+    const float s4 = a00 * g.a0s + a01 * g.b0s + a10 * g.a1s + a11 * g.b1s;
+    const fdn_v2f zero = {0.f, 0.f};
+    fdn_v2f r23v = inside ? s01 : zero;                       // (r2, r3)
+    fdn_v2f r45 = inside ? (r23 + s23) * 0.5f : r23;          // (r4, r5)
+    float r6 = inside ? (r4c + s4) * 0.25f : r4c * 0.5f;
+    r23v = (r01 - r23v) * 0.5f;
+    r23v.x = r23v.x + (r45.x * dy + r6 * dx);
+    r23v.y = r23v.y + (r6 * dy + r45.y * dx);
     if (any_damp) {
-        float scale = damp ? bxx * by0 * by1 : 1.f;
-        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+        const float scale = damp ? bxx * by0 * by1 : 1.f;
+        r23v *= scale; r45 *= scale; r6 *= scale;
     }
-    m[0] = r4 * r4 + r6 * r6;
-    m[1] = (r4 + r5) * r6;
-    m[2] = r5 * r5 + r6 * r6;
-    m[3] = r4 * r2 + r6 * r3;
-    m[4] = r6 * r2 + r5 * r3;
+    const float r66 = r6 * r6;
+    m02 = r45 * r45 + r66;                                    // (r4 r4 + r6 r6, r5 r5 + r6 r6)
+    m1 = (r45.x + r45.y) * r6;
+    const fdn_v2f p = r45 * r23v;                             // (r4 r2, r5 r3)
+    const fdn_v2f q = r6 * r23v.yx;                           // (r6 r3, r6 r2)
+    m34.x = p.x + q.x;                                        // r4 r2 + r6 r3
+    m34.y = q.y + p.y;                                        // r6 r2 + r5 r3
 }
 
-static __device__ __forceinline__ void compute_M(const float r0[5], const float* __restrict__ R1, size_t HW,
-                                                 int H, int W, int x, int y, float dx, float dy, float m[5])
+// FarnebackUpdateMatrices for one pixel (the per-stage kernels): m[5] = M at (x, y) for flow (dx, dy)
+static __device__ __forceinline__ void compute_M(const RImage& R0, const RImage& R1, int H, int W, int x, int y,
+                                                 float dx, float dy, float m[5])
 {
+    fdn_v2f r01, r23; float r4;
+    load_R(R0, (unsigned)y * (unsigned)W + (unsigned)x, r01, r23, r4);
     int x1, y1; float fx, fy;
-    flow_target(x, y, dx, dy, x1, y1, fx, fy);
-    GatherTaps g;
-    gather_R1(R1, HW, H, W, x1, y1, g);
+    flow_target((float)x, (float)y, dx, dy, x1, y1, fx, fy);
+    GatherTapsP g;
+    gather_R1_p(R1, H, W, x1, y1, g);
     float by0 = y < 5 ? (y < 2 ? 0.14f : 0.4472f) : 1.f;
     float by1 = y >= H - 5 ? (H - y - 1 < 2 ? 0.14f : 0.4472f) : 1.f;
-    finish_M(r0, g, H, W, x1, y1, fx, fy, dx, dy, border_factor(x, W), by0, by1, border_test(x, W) || border_test(y, H), m);
+    fdn_v2f m02, m34;
+    finish_M_p(r01, r23, r4, g, H, W, x1, y1, fx, fy, dx, dy, border_factor(x, W), by0, by1,
+               border_test(x, W) || border_test(y, H), true, m02, m[1], m34);
+    m[0] = m02.x; m[2] = m02.y; m[3] = m34.x; m[4] = m34.y;
 }
 
 static __device__ __forceinline__ float2 solve_flow(const double a[5], double scale)

@@ -82,9 +82,12 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
     constexpr int BW = 64 - 2 * HALO;
     constexpr int NRP = (ITERS - 1) * STEP + 2 * D + 2;   // window rows [t-2 STEP-D, t+D] + the one being loaded
     constexpr int WC = 64 + 2 * DX;               // D: window half-height (rows), DX: half-width (columns)
-    constexpr int WCP = WC + 1;                  // odd row pitch: lanes reading different rows spread over the banks
+    // window row = [ (c0,c1) x WCP ][ (c2,c3) x WCP ][ c4 x WCP ] floats (the RImage layout): pitch 5 WCP, kept
+    // even (8-byte aligned pairs) and away from multiples of 16 banks so that lanes reading different rows spread
+    constexpr int WCP = (5 * WC) % 16 == 0 ? WC + 2 : WC;
+    static_assert(WC % 2 == 0, "pair planes need an even pitch");
     __shared__ float Mx[ITERS][2][5][64];        // hand-over slots: row r of M_k lives in slot r & 1 for one step
-    extern __shared__ float win[];               // [NRP][5][WCP] (dynamic: sized by the launcher)
+    extern __shared__ __attribute__((aligned(16))) float win[];   // [NRP][5 WCP] (dynamic: sized by the launcher)
 
     const int lane = threadIdx.x & 63;
     const int stage = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -103,10 +106,9 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
     const size_t HW = (size_t)H * W;
     const float* R0 = Rstack + (size_t)(pb.t0 + b) * 5 * HW;
     const float* R1 = Rstack + (size_t)(pb.t0 + b + pb.d) * 5 * HW;
-    const float* R0p[5];
-    const float* R1p[5];
-#pragma unroll
-    for (int c = 0; c < 5; c++) { R0p[c] = uniform_ptr(R0 + c * HW); R1p[c] = uniform_ptr(R1 + c * HW); }
+    // opaque wave-uniform plane bases: every access is SGPR base + 32-bit per-lane byte offset
+    const RImage R0i = {uniform_ptr(R0), uniform_ptr(R0 + 2 * HW), uniform_ptr(R0 + 4 * HW)};
+    const RImage R1i = {uniform_ptr(R1), uniform_ptr(R1 + 2 * HW), uniform_ptr(R1 + 4 * HW)};
     const float bxx = border_factor(xc, W);
     const bool xdamp = border_test(xc, W);
     const int xw0 = xb - DX;                     // image column of window column 0
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
     };
     // Bilinear taps for a stage working on row ys.  `need`: lanes whose result is used.  Fast path:
     // the lane's 2x2 footprint lies in window rows [ys-D, ys+D] and the window's columns.
-    auto gather = [&](int ys, int x1, int y1, bool need, GatherTaps& g) __attribute__((always_inline)) {
+    auto gather = [&](int ys, int x1, int y1, bool need, GatherTapsP& g) __attribute__((always_inline)) {
         const int x1c = clampi(x1, 0, W - 2), y1c = clampi(y1, 0, H - 2);
         int col = x1c - xw0;
         int dy = y1c - (ys - D);
@@ -138,29 +140,35 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
         s0 = min(s0, s0 - (unsigned)NRP);
         unsigned s1 = s0 + 1u;
         s1 = min(s1, s1 - (unsigned)NRP);
-        const float* q0 = win + __umul24(s0, 5u * WCP) + col;
-        const float* q1 = win + __umul24(s1, 5u * WCP) + col;
+        // (a, b) = columns (col, col + 1) of both channels of a pair: 16 contiguous bytes -> ds_read2_b64
+        const float* q0 = win + __umul24(s0, 5u * WCP) + 2 * col;
+        const float* q1 = win + __umul24(s1, 5u * WCP) + 2 * col;
 #pragma unroll
-        for (int c = 0; c < 5; c++) {
-            g.t0[c].a = q0[c * WCP]; g.t0[c].b = q0[c * WCP + 1];
-            g.t1[c].a = q1[c * WCP]; g.t1[c].b = q1[c * WCP + 1];
+        for (int q = 0; q < 2; q++) {
+            g.a0[q] = *(const fdn_v2f*)(q0 + 2 * q * WCP); g.b0[q] = *(const fdn_v2f*)(q0 + 2 * q * WCP + 2);
+            g.a1[q] = *(const fdn_v2f*)(q1 + 2 * q * WCP); g.b1[q] = *(const fdn_v2f*)(q1 + 2 * q * WCP + 2);
         }
+        g.a0s = q0[4 * WCP - col]; g.b0s = q0[4 * WCP - col + 1];
+        g.a1s = q1[4 * WCP - col]; g.b1s = q1[4 * WCP - col + 1];
         if (__any(miss)) {       // a flow that leaves the window: those lanes (only) go to global memory
-            if (miss) gather_R1_planes(R1p, H, W, x1, y1, g);
+            if (miss) gather_R1_p(R1i, H, W, x1, y1, g);
         }
     };
     const float xf = (float)xc;
     // no lane of this band is within 5 columns of an image edge (then rows 5 .. H-6 need no damping at all)
     const bool band_nodamp = xb >= 5 && xb + 63 <= W - 6;
-    auto update_matrices = [&](int ys, float2 f, const float r0[5], bool need, float mm[5]) __attribute__((always_inline)) {
+    struct R0Px { fdn_v2f r01, r23; float r4; };     // R0 at one pixel
+    auto update_matrices = [&](int ys, float2 f, const R0Px& r0, bool need, float mm[5]) __attribute__((always_inline)) {
         int x1, y1; float fx, fy;
         flow_target(xf, (float)ys, f.x, f.y, x1, y1, fx, fy);
-        GatherTaps g;
+        GatherTapsP g;
         gather(ys, x1, y1, need, g);
         float by0, by1;
         row_factor(ys, by0, by1);
         const bool any_damp = !(band_nodamp && ys >= 5 && ys < H - 5);
-        finish_M(r0, g, H, W, x1, y1, fx, fy, f.x, f.y, bxx, by0, by1, xdamp || border_test(ys, H), mm, any_damp);
+        fdn_v2f m02, m34;
+        finish_M_p(r0.r01, r0.r23, r0.r4, g, H, W, x1, y1, fx, fy, f.x, f.y, bxx, by0, by1, xdamp || border_test(ys, H), any_damp, m02, mm[1], m34);
+        mm[0] = m02.x; mm[2] = m02.y; mm[3] = m34.x; mm[4] = m34.y;
     };
 
     const int T = H + ITERS * STEP;              // row steps = barriers every wave executes
@@ -178,49 +186,48 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
         };
         const int wcol0 = clampi(xw0 + lane, 0, W - 1);        // image columns this lane loads into the window
         const int wcol1 = clampi(xw0 + 64 + lane, 0, W - 1);
-        auto load_window_row = [&](int v, float w0[5], float w1[5]) __attribute__((always_inline)) {
+        struct WinRow { fdn_v2f a01, a23, b01, b23; float a4, b4; };   // columns wcol0 (a) and wcol1 (b) of one R1 row
+        auto load_window_row = [&](int v, WinRow& w) __attribute__((always_inline)) {
             const unsigned vo = (unsigned)v * (unsigned)W;
-#pragma unroll
-            for (int c = 0; c < 5; c++) { w0[c] = ld_off<float>(R1p[c], (vo + wcol0) * 4u); w1[c] = ld_off<float>(R1p[c], (vo + wcol1) * 4u); }
+            load_R(R1i, vo + wcol0, w.a01, w.a23, w.a4);
+            load_R(R1i, vo + wcol1, w.b01, w.b23, w.b4);
         };
-        auto store_window_row = [&](int v, const float w0[5], const float w1[5]) __attribute__((always_inline)) {
-            const int s = v % NRP;
-#pragma unroll
-            for (int c = 0; c < 5; c++) win[((size_t)s * 5 + c) * WCP + lane] = w0[c];
+        auto store_window_row = [&](int v, const WinRow& w) __attribute__((always_inline)) {
+            float* row = win + (size_t)(v % NRP) * 5 * WCP;
+            *(fdn_v2f*)(row + 2 * lane) = w.a01;
+            *(fdn_v2f*)(row + 2 * WCP + 2 * lane) = w.a23;
+            row[4 * WCP + lane] = w.a4;
             if (lane < 2 * DX) {
-#pragma unroll
-                for (int c = 0; c < 5; c++) win[((size_t)s * 5 + c) * WCP + 64 + lane] = w1[c];
+                *(fdn_v2f*)(row + 2 * (64 + lane)) = w.b01;
+                *(fdn_v2f*)(row + 2 * WCP + 2 * (64 + lane)) = w.b23;
+                row[4 * WCP + 64 + lane] = w.b4;
             }
         };
         {   // rows 0..D before the first step
-            float w0[5], w1[5];
-            for (int v = 0; v <= (D < H - 1 ? D : H - 1); v++) { load_window_row(v, w0, w1); store_window_row(v, w0, w1); }
+            WinRow w;
+            for (int v = 0; v <= (D < H - 1 ? D : H - 1); v++) { load_window_row(v, w); store_window_row(v, w); }
         }
         // operands of row 0, then always one row ahead
         float2 fN = load_flow(0);
-        float r0N[5];
-#pragma unroll
-        for (int c = 0; c < 5; c++) r0N[c] = ld_off<float>(R0p[c], xc * 4u);
+        R0Px r0N;
+        load_R(R0i, (unsigned)xc, r0N.r01, r0N.r23, r0N.r4);
         lds_barrier();
         for (int t = 0; t < T; t++) {
             if (t < H) {
                 const float2 f = fN;
-                float r0[5];
-#pragma unroll
-                for (int c = 0; c < 5; c++) r0[c] = r0N[c];
+                const R0Px r0 = r0N;
                 const int tn = t + 1 < H ? t + 1 : H - 1;
                 const unsigned on = (unsigned)tn * (unsigned)W + (unsigned)xc;
                 fN = load_flow(tn);
-#pragma unroll
-                for (int c = 0; c < 5; c++) r0N[c] = ld_off<float>(R0p[c], on * 4u);
+                load_R(R0i, on, r0N.r01, r0N.r23, r0N.r4);
                 const int vnext = t + D + 1;                 // window row the next step needs
-                float wl0[5], wl1[5];
-                load_window_row(vnext < H ? vnext : H - 1, wl0, wl1);
+                WinRow wl;
+                load_window_row(vnext < H ? vnext : H - 1, wl);
                 float mm[5];
                 update_matrices(t, f, r0, in_img, mm);
 #pragma unroll
                 for (int c = 0; c < 5; c++) Mx[0][t & 1][c][lane] = mm[c];
-                if (vnext < H) store_window_row(vnext, wl0, wl1);
+                if (vnext < H) store_window_row(vnext, wl);
             }
             lds_barrier();
         }
@@ -310,9 +317,9 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
                     }
                     const float2 f = solve_flow(a, scale);
                     if (K < ITERS) {
-                        float r0[5], mm[5];
-#pragma unroll
-                        for (int c = 0; c < 5; c++) r0[c] = ld_off<float>(R0p[c], o * 4u);
+                        float mm[5];
+                        R0Px r0;
+                        load_R(R0i, o, r0.r01, r0.r23, r0.r4);
                         update_matrices(y, f, r0, need, mm);
 #pragma unroll
                         for (int c = 0; c < 5; c++) Mx[K < ITERS ? K : 0][y & 1][c][lane] = mm[c];
@@ -373,7 +380,8 @@ static void launch_variant(const float* Rstack, const float* stack, const float*
                            PairBatch pb, int H, int W, double scale, double weight, int nbands, long blocks, FlowSource fs, hipStream_t st)
 {
     constexpr int MH = 2, D = FusedVariant<OCC>::D, DX = FusedVariant<OCC>::DX, U = FusedVariant<OCC>::U;
-    constexpr unsigned win_bytes = (2 * (MH + 1) + 2 * D + 2) * 5 * (64 + 2 * DX + 1) * sizeof(float);
+    constexpr int WC = 64 + 2 * DX, WCP = (5 * WC) % 16 == 0 ? WC + 2 : WC;   // as in the kernel
+    constexpr unsigned win_bytes = (2 * (MH + 1) + 2 * D + 2) * 5 * WCP * sizeof(float);
     // a CU's 160 KB of LDS is handed out in 2 KB granules
     static_assert(win_bytes + 3 * 2 * 5 * 64 * sizeof(float) <= (160 * 1024 / OCC) / 2048 * 2048, "LDS per workgroup");
     dim3 grid((unsigned)blocks);

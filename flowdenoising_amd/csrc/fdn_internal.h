@@ -28,7 +28,8 @@ void prepare_blur_taps(int n, double sigma, BlurTaps* bt);
 // ---- launchers: all asynchronous on `st`, all pointers are device pointers ----------
 
 // R[s] = polyexp(blur3x3(img[s])) for s in [0, nslices): img slices are H*W apart,
-// R slices are 5*H*W apart (planar: plane c of slice s at R + (s*5 + c)*H*W).
+// R slices are 5*H*W floats apart, each in the RImage layout of fdn_device.h
+// ([(c0,c1) x HW][(c2,c3) x HW][c4 x HW]).
 void launch_blur3_polyexp(const float* img, float* R, int nslices, int H, int W,
                           const PolyConsts& pc, hipStream_t st);
 // same without the fused 3x3 blur (pyramid levels: the input is already blurred+resized)

@@ -9,9 +9,9 @@
 // oracle/fdn_oracle.c for the restatement and the reference call sites,
 // src/flowdenoising_sequential.py:56,62); the file is compiled with -ffp-contract=off so
 // that the compiler does not fuse multiplies and adds the CPU code keeps separate.
-// Layouts: images [H][W] f32; polynomial expansion R and matrices M are PLANAR,
-// 5 planes of [H][W] (coalesced along x for both the aligned reads and the bilinear
-// gathers); flow is interleaved (x,y) float2 as in cv2.
+// Layouts: images [H][W] f32; polynomial expansion R: channel pairs (0,1), (2,3) interleaved +
+// channel 4 planar (RImage, fdn_device.h); matrices M: 5 planes of [H][W]; flow: interleaved
+// (x,y) float2 as in cv2.
 #include "fdn_internal.h"
 #include "fdn_device.h"
 
@@ -91,10 +91,9 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img_b
             b5 += (double)((a2[k] + a2[-k]) * gk);
         }
         size_t o = (size_t)y * W + x;
-        R[o] = (float)(b3 * pc.ig11);
-        R[HW + o] = (float)(b2 * pc.ig11);
-        R[2 * HW + o] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
-        R[3 * HW + o] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+        // channel pairs (0,1), (2,3) interleaved, channel 4 planar (RImage, fdn_device.h)
+        ((float2*)R)[o] = make_float2((float)(b3 * pc.ig11), (float)(b2 * pc.ig11));
+        ((float2*)(R + 2 * HW))[o] = make_float2((float)(b1 * pc.ig03 + b5 * pc.ig33), (float)(b1 * pc.ig03 + b4 * pc.ig33));
         R[4 * HW + o] = (float)(b6 * pc.ig55);
     }
 }
@@ -117,19 +116,17 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict
 {
     const size_t HW = (size_t)H * W;
     const int b = blockIdx.z;
-    const float* R0 = Rstack + (size_t)(pb.t0 + b) * 5 * HW;
-    const float* R1 = Rstack + (size_t)(pb.t0 + b + pb.d) * 5 * HW;
+    const RImage R0 = r_image(Rstack + (size_t)(pb.t0 + b) * 5 * HW, HW);
+    const RImage R1 = r_image(Rstack + (size_t)(pb.t0 + b + pb.d) * 5 * HW, HW);
     const float2* flow = (const float2*)flow_base + (size_t)b * HW;
     float* M = M_base + (size_t)b * 5 * HW;
     int x = blockIdx.x * 64 + (threadIdx.x & 63);
     int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     size_t o = (size_t)y * W + x;
-    float r0[5], m[5];
-#pragma unroll
-    for (int c = 0; c < 5; c++) r0[c] = R0[c * HW + o];
+    float m[5];
     float2 f = flow[o];
-    compute_M(r0, R1, HW, H, W, x, y, f.x, f.y, m);
+    compute_M(R0, R1, H, W, x, y, f.x, f.y, m);
 #pragma unroll
     for (int c = 0; c < 5; c++) M[c * HW + o] = m[c];
 }
@@ -199,8 +196,8 @@ __global__ __launch_bounds__(256) void k_update_flow_scan(const float* __restric
         for (int c = 0; c < 5; c++) vs[c] += (double)(p1[c * HW] - p0[c * HW]);
     }
     const bool owner = lane >= m && lane < 64 - m && x < W;
-    const float* R0 = Rstack + (size_t)(pb.t0 + b) * 5 * HW;
-    const float* R1 = Rstack + (size_t)(pb.t0 + b + pb.d) * 5 * HW;
+    const RImage R0 = r_image(Rstack + (size_t)(pb.t0 + b) * 5 * HW, HW);
+    const RImage R1 = r_image(Rstack + (size_t)(pb.t0 + b + pb.d) * 5 * HW, HW);
     float2* flow = (float2*)flow_base + (size_t)b * HW;
     float* Mout = Mout_base ? Mout_base + (size_t)b * 5 * HW : nullptr;
 
@@ -229,10 +226,8 @@ __global__ __launch_bounds__(256) void k_update_flow_scan(const float* __restric
             size_t o = (size_t)y * W + x;
             flow[o] = f;
             if (Mout) {
-                float r0[5], mm[5];
-#pragma unroll
-                for (int c = 0; c < 5; c++) r0[c] = R0[c * HW + o];
-                compute_M(r0, R1, HW, H, W, x, y, f.x, f.y, mm);
+                float mm[5];
+                compute_M(R0, R1, H, W, x, y, f.x, f.y, mm);
 #pragma unroll
                 for (int c = 0; c < 5; c++) Mout[c * HW + o] = mm[c];
             }
@@ -273,8 +268,8 @@ __global__ __launch_bounds__(256) void k_update_flow_scan_t(const float* __restr
         for (int c = 0; c < 5; c++) vs[c] += (double)(p1[c * HW] - p0[c * HW]);
     }
     const bool owner = lane >= M && lane < 64 - M && x < W;
-    const float* R0 = Rstack + (size_t)(pb.t0 + b) * 5 * HW;
-    const float* R1 = Rstack + (size_t)(pb.t0 + b + pb.d) * 5 * HW;
+    const RImage R0 = r_image(Rstack + (size_t)(pb.t0 + b) * 5 * HW, HW);
+    const RImage R1 = r_image(Rstack + (size_t)(pb.t0 + b + pb.d) * 5 * HW, HW);
     float2* flow = (float2*)flow_base + (size_t)b * HW;
     float* Mout = Mout_base ? Mout_base + (size_t)b * 5 * HW : nullptr;
 
@@ -305,10 +300,8 @@ __global__ __launch_bounds__(256) void k_update_flow_scan_t(const float* __restr
             size_t o = (size_t)y * W + x;
             flow[o] = f;
             if (Mout) {
-                float r0[5], mm[5];
-#pragma unroll
-                for (int c = 0; c < 5; c++) r0[c] = R0[c * HW + o];
-                compute_M(r0, R1, HW, H, W, x, y, f.x, f.y, mm);
+                float mm[5];
+                compute_M(R0, R1, H, W, x, y, f.x, f.y, mm);
 #pragma unroll
                 for (int c = 0; c < 5; c++) Mout[c * HW + o] = mm[c];
             }
