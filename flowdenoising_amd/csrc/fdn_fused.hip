@@ -276,12 +276,12 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
             const int n = y + MH;
             if (y < H) {
                 {
-                    const bool fresh = n <= H - 1;
-                    const int sl = fresh ? (n & 1) : 0;
+                    if (n <= H - 1) {          // take over the row the producer wrote in the previous step
 #pragma unroll
-                    for (int c = 0; c < 5; c++) {
-                        const float m = Min[sl][c][lane];
-                        e[at(0)][c] = fresh ? m : e[at(1)][c];
+                        for (int c = 0; c < 5; c++) e[at(0)][c] = Min[n & 1][c][lane];
+                    } else {                   // below the image: row H-1 again
+#pragma unroll
+                        for (int c = 0; c < 5; c++) e[at(0)][c] = e[at(1)][c];
                     }
                 }
                 if (y >= 0) {
