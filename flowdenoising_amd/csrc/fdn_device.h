@@ -134,13 +134,12 @@ static __device__ __forceinline__ void flow_target(float xf, float yf, float dx,
 // FarnebackUpdateMatrices for one pixel from its operands: (r01, r23, r4c) = R0 at the pixel, g = the
 // neighbour expansion's 2 x 2 footprint at (x1, y1) = floor(p + flow), (fx, fy) the fractions (exact f32
 // weights, no quantisation), (dx, dy) the flow.  The gather ran at a clamped position; the
-// out-of-image case is a select here.  `any_damp` (wave-uniform; false only when no lane has `damp`)
-// skips the multiplications by the border factor where it is 1.0f.  Channel pairs stay packed
+// out-of-image case is a select here.  Channel pairs stay packed
 // (v_pk_* f32); element-wise the operations and their order are those of OpenCV's scalar loop, so the
 // values are bit-identical to the CPU form.  Result: M as (m0, m2), m1, (m3, m4).
 static __device__ __forceinline__ void finish_M_p(fdn_v2f r01, fdn_v2f r23, float r4c, const GatherTapsP& g, int H, int W, int x1, int y1,
                                                   float fx, float fy, float dx, float dy, float bxx, float by0, float by1,
-                                                  bool damp, bool any_damp, fdn_v2f& m02, float& m1, fdn_v2f& m34)
+                                                  bool damp, fdn_v2f& m02, float& m1, fdn_v2f& m34)
 {
     const bool inside = (unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1);
     const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
@@ -154,10 +153,11 @@ static __device__ __forceinline__ void finish_M_p(fdn_v2f r01, fdn_v2f r23, floa
     r23v = (r01 - r23v) * 0.5f;
     r23v.x = r23v.x + (r45.x * dy + r6 * dx);
     r23v.y = r23v.y + (r6 * dy + r45.y * dx);
-    if (any_damp) {
-        const float scale = damp ? bxx * by0 * by1 : 1.f;
-        r23v *= scale; r45 *= scale; r6 *= scale;
-    }
+    // ((bx0*bx1)*by0)*by1 as OpenCV, == 1.0f away from the border.  `damp` is OpenCV's own region test
+    // ((unsigned)(x-5) >= (unsigned)(W-10) || same for y): for images under 10 pixels it is NOT
+    // "within 5 pixels of an edge" (the unsigned difference wraps), and the factors are skipped.
+    const float scale = damp ? bxx * by0 * by1 : 1.f;
+    r23v *= scale; r45 *= scale; r6 *= scale;
     const float r66 = r6 * r6;
     m02 = r45 * r45 + r66;                                    // (r4 r4 + r6 r6, r5 r5 + r6 r6)
     m1 = (r45.x + r45.y) * r6;
@@ -181,7 +181,7 @@ static __device__ __forceinline__ void compute_M(const RImage& R0, const RImage&
     float by1 = y >= H - 5 ? (H - y - 1 < 2 ? 0.14f : 0.4472f) : 1.f;
     fdn_v2f m02, m34;
     finish_M_p(r01, r23, r4, g, H, W, x1, y1, fx, fy, dx, dy, border_factor(x, W), by0, by1,
-               border_test(x, W) || border_test(y, H), true, m02, m[1], m34);
+               border_test(x, W) || border_test(y, H), m02, m[1], m34);
     m[0] = m02.x; m[2] = m02.y; m[3] = m34.x; m[4] = m34.y;
 }
 

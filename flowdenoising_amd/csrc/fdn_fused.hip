@@ -155,8 +155,6 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
         }
     };
     const float xf = (float)xc;
-    // no lane of this band is within 5 columns of an image edge (then rows 5 .. H-6 need no damping at all)
-    const bool band_nodamp = xb >= 5 && xb + 63 <= W - 6;
     struct R0Px { fdn_v2f r01, r23; float r4; };     // R0 at one pixel
     auto update_matrices = [&](int ys, float2 f, const R0Px& r0, bool need, float mm[5]) __attribute__((always_inline)) {
         int x1, y1; float fx, fy;
@@ -165,9 +163,8 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
         gather(ys, x1, y1, need, g);
         float by0, by1;
         row_factor(ys, by0, by1);
-        const bool any_damp = !(band_nodamp && ys >= 5 && ys < H - 5);
         fdn_v2f m02, m34;
-        finish_M_p(r0.r01, r0.r23, r0.r4, g, H, W, x1, y1, fx, fy, f.x, f.y, bxx, by0, by1, xdamp || border_test(ys, H), any_damp, m02, mm[1], m34);
+        finish_M_p(r0.r01, r0.r23, r0.r4, g, H, W, x1, y1, fx, fy, f.x, f.y, bxx, by0, by1, xdamp || border_test(ys, H), m02, mm[1], m34);
         mm[0] = m02.x; mm[2] = m02.y; mm[3] = m34.x; mm[4] = m34.y;
     };
 
