@@ -793,6 +793,8 @@ FDN_API int fdn_warp(fdn_handle h, const float* reference, const float* flow, fl
     FDN_ENTER(h);
     if (!reference || !flow || !dst) return fail("NULL pointer");
     if (H <= 0 || W <= 0) return fail("bad image dims");
+    if (H >= (1 << 24) || W >= (1 << 24) || (size_t)H * W >= ((size_t)1 << 29))
+        return fail("images of %dx%d pixels are not supported (limit: 2^29 pixels per image)", W, H);
     const size_t HW = (size_t)H * W;
     hipStream_t st = h->stream;
     if (ensure(h, h->pair, HW * 4 * 4)) return -1;

@@ -240,7 +240,7 @@ static __device__ __forceinline__ void remap_issue(const float* __restrict__ src
     int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);
     int xa = clampi(ix, 0, W - 1), xb = clampi(ix + 1, 0, W - 1);
     int ya = clampi(iy, 0, H - 1), yb = clampi(iy + 1, 0, H - 1);
-    const unsigned oa = (unsigned)ya * (unsigned)W, ob = (unsigned)yb * (unsigned)W;
+    const unsigned oa = __umul24((unsigned)ya, (unsigned)W), ob = __umul24((unsigned)yb, (unsigned)W);   // H, W < 2^24
     r.v0 = ld_off<float>(src, (oa + xa) * 4u); r.v1 = ld_off<float>(src, (oa + xb) * 4u);
     r.v2 = ld_off<float>(src, (ob + xa) * 4u); r.v3 = ld_off<float>(src, (ob + xb) * 4u);
 }

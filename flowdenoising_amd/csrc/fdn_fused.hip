@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
         // ===== wave 0: stage A + the R1 window stream ==============================================
         // FIN 0: zero flow; 1: flow_in is this level's flow; 2: flow_in is the next coarser level's
         // (fs.h x fs.w) result, resized INTER_LINEAR and doubled on the fly (calc()'s upsampling)
-        const float* flow_in = FIN == 1 ? flow_in_base + (size_t)b * HW * 2 : FIN == 2 ? flow_in_base + (size_t)b * fs.h * fs.w * 2 : nullptr;
+        const float* flow_in = FIN == 1 ? uniform_ptr(flow_in_base + (size_t)b * HW * 2) : FIN == 2 ? uniform_ptr(flow_in_base + (size_t)b * fs.h * fs.w * 2) : nullptr;
         const LinearTap ftx = FIN == 2 ? linear_tap(xc, fs.sx, fs.w) : LinearTap{};
         auto load_flow = [&](int row) __attribute__((always_inline)) -> float2 {
             if (FIN == 1) return ld_off<float2>(flow_in, ((unsigned)row * (unsigned)W + (unsigned)xc) * 8u);
@@ -237,9 +237,9 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
     // -> DPP -> f64-add chains then interleave instead of running one after the other.
     const bool edge_band = xb < MH || xb + 63 + MH > W - 1;   // a window column of some lane is outside the image
     const bool owner = lane >= HALO && lane < 64 - HALO && x < W;
-    const float* img1 = ACC ? stack + (size_t)(pb.t0 + b + pb.d) * HW : nullptr;
-    float2* flow_out = flow_out_base ? (float2*)flow_out_base + (size_t)b * HW : nullptr;
-    float* acc = ACC ? acc_base + (size_t)b * HW : nullptr;
+    const float* img1 = ACC ? uniform_ptr(stack + (size_t)(pb.t0 + b + pb.d) * HW) : nullptr;
+    float2* flow_out = flow_out_base ? uniform_ptr((float2*)flow_out_base + (size_t)b * HW) : nullptr;
+    float* acc = ACC ? uniform_ptr(acc_base + (size_t)b * HW) : nullptr;
 
     auto stage_loop = [&](auto KT, auto ET) __attribute__((always_inline)) {
         constexpr int K = decltype(KT)::value;
