@@ -83,7 +83,7 @@ def _run(world, shape, sigmas, border_mode=0, use_of=True):
     return res
 
 
-@pytest.mark.parametrize("world,shape", [(2, (12, 34, 36)), (3, (11, 34, 37))])
+@pytest.mark.parametrize("world,shape", [(2, (12, 34, 36)), (3, (11, 34, 37)), (4, (10, 33, 35))])
 def test_sharded_of_filter_equals_single_process(oracle, world, shape):
     from flowdenoising_amd.synth import make_volume
     sig = (1.0, 0.5, 1.0)
