@@ -169,3 +169,32 @@ def test_full_size_identical_slices(fdn):
     for i in order:
         acc = (acc.astype(np.float64) + img.astype(np.float64) * k[i]).astype(np.float32)
     assert np.array_equal(got[12, :900, :900], acc[:900, :900])
+
+
+def test_wide_kernel_on_a_gib_volume_spot_parity(fdn, oracle):
+    """BASELINE.json configs[3] on one GPU: 1024 x 1024 x 1024 float32, sigma = 4 (K = 33, chains of 16
+    steps either side), volume resident in HBM; the Z pass is spot-checked against the oracle run on
+    the 33-slice sub-volume that feeds one target slice."""
+    import torch
+    from flowdenoising_amd import _lib, synth
+    shape = (1024, 1024, 1024)
+    dev = torch.device("cuda", 0)
+    vol = synth.make_volume(shape, seed=1234 + 4, amplitude=100.0, xp=torch, device=dev)
+    out = torch.empty_like(vol)
+    h = _lib.Handle(0)
+    try:
+        h.set_stream(torch.cuda.current_stream().cuda_stream)
+        k = _lib.gaussian_kernel(4.0)
+        params = _lib.SweepParams(0, 5, 3, 5, 1.2, _lib.BORDER_MEAN_PAD, 1, 1)
+        mean = h.mean_dev(vol.data_ptr(), vol.numel())
+        h.filter_3d_dev(vol.data_ptr(), out.data_ptr(), shape, [k, None, None], mean, params)
+        torch.cuda.synchronize()
+        t = 500
+        sub = vol[t - 16:t + 17].cpu().numpy()
+        got = out[t].cpu().numpy()
+    finally:
+        h.close()
+        del vol, out
+        torch.cuda.empty_cache()
+    want = oracle.filter_axis_range(sub, 0, k, 0, 5, mean, 16, 17, nthreads=16)
+    assert np.array_equal(got, want[16])
