@@ -21,7 +21,8 @@
 //                consumer takes it over into a six-row delay line in VGPRs (its own column of rows
 //                y-3 .. y+2 is all the running sum needs), so the matrices never reach HBM and cost
 //                7.7 KB of LDS instead of 3 x 7 rows
-//     R1 window  [rows t-2(MH+1)-D .. t+D+1][5][64+2DX+1]  (dynamic LDS, D = 7 rows, DX = 5 columns)
+//     R1 window  [rows t-2(MH+1)-D .. t+D+1][5 (64+2DX)]  (dynamic LDS, D = 7 rows, DX = 5 columns; a row holds
+//                channel pairs (0,1), (2,3) interleaved and channel 4, the RImage layout of fdn_device.h)
 //                neighbour expansion: every stage gathers its bilinear taps here.  The flows of noisy
 //                volumes span several pixels, so lanes of one wave read different ROWS: from global
 //                memory that is one cache line per lane and instruction (27 % of the kernel's time
@@ -33,7 +34,7 @@
 //   Each iteration loses MH columns of validity either side: a band yields 64 - 6 MH = 52 output
 //   columns for winsize 5; windows that reach outside the image read the lane of the clamped
 //   column, which is BORDER_REPLICATE of the running sums.
-//   Measured (MI355X, 512 targets of 1024 x 1024): 18.1 ms per launch, VALU issue 93 % busy
+//   Measured (MI355X, 512 targets of 1024 x 1024): 17.1 ms per launch, VALU issue 86 % busy
 //   (DESIGN.md 3.2 has the history and the variants that lost).
 #include "fdn_internal.h"
 #include "fdn_device.h"
@@ -368,9 +369,9 @@ bool fused_supported(int winsize, int iters, int H, int W)
 // One build of the kernel per occupancy: LDS window size, unroll and VGPR budget chosen for OCC
 // workgroups per CU.  (ms per launch of 512 targets of 1024 x 1024 = 10240 workgroups on MI355X.)
 template <int OCC> struct FusedVariant;
-template <> struct FusedVariant<3> { static constexpr int D = 8, DX = 8, U = 3; };   // 46.6 KB [18.9]
-template <> struct FusedVariant<4> { static constexpr int D = 7, DX = 5, U = 3; };   // 40.7 KB [18.1]
-template <> struct FusedVariant<5> { static constexpr int D = 4, DX = 5, U = 1; };   // 31.7 KB, 96 VGPRs
+template <> struct FusedVariant<3> { static constexpr int D = 8, DX = 8, U = 3; };   // 47.0 KB [18.1]
+template <> struct FusedVariant<4> { static constexpr int D = 7, DX = 5, U = 3; };   // 40.2 KB [17.2]
+template <> struct FusedVariant<5> { static constexpr int D = 4, DX = 5, U = 1; };   // 31.4 KB, 96 VGPRs [18.0]
 
 template <int OCC>
 static void launch_variant(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
@@ -399,8 +400,8 @@ static void launch_variant(const float* Rstack, const float* stack, const float*
 }
 
 // Workgroups per CU for a grid of `blocks` workgroups.  All workgroups of a launch take about the same
-// time, so what counts is the number of rounds: large grids run fastest at 4 per CU [18.6 ms for
-// 10240 workgroups against 19.2 at 3 and 19.9 at 5], but a grid that fits one round at 5 and not at 4
+// time, so what counts is the number of rounds: large grids run fastest at 4 per CU [17.2 ms for
+// 10240 workgroups against 18.1 at 3 and 18.0 at 5], but a grid that fits one round at 5 and not at 4
 // -- 1280 workgroups: the 64-slice Z slab of an 8-GPU run -- gains 16 % there [2.69 against 3.21 ms].
 // Measured no better: 5 per CU for 2560 workgroups (2 rounds instead of 3), 3 per CU anywhere.
 static int choose_occupancy(long blocks)
