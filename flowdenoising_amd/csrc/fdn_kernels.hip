@@ -38,13 +38,15 @@ static __device__ __forceinline__ float blur3_at(const float* __restrict__ img, 
     return 0.5f * t[1] + 0.25f * (t[2] + t[0]);
 }
 
-template <bool FUSE_BLUR3>
+// NT: the neighbourhood half-width when known at compile time (5: the reference's poly_n; loops unroll,
+// index divisions become multiplications), 0: taken from pc.n.
+template <bool FUSE_BLUR3, int NT>
 __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img_base, float* __restrict__ R_base,
                                                  int H, int W, PolyConsts pc)
 {
     __shared__ float sB[(PE_TH + 2 * PE_MAXN) * (PE_TW + 2 * PE_MAXN)];
     __shared__ float sRow[3][PE_TH][PE_TW + 2 * PE_MAXN];
-    const int n = pc.n;
+    const int n = NT ? NT : pc.n;
     const int LW = PE_TW + 2 * n, LH = PE_TH + 2 * n;
     const size_t HW = (size_t)H * W;
     const float* img = img_base + (size_t)blockIdx.z * HW;
@@ -61,6 +63,7 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img_b
         int ry = idx / LW, tx = idx - ry * LW;
         const float* c = sB + (ry + n) * LW + tx;
         float r0 = c[0] * pc.g[0], r1 = 0.f, r2 = 0.f;
+#pragma unroll
         for (int k = 1; k <= n; k++) {
             float s0 = c[-k * LW], s1 = c[k * LW];
             float p = s0 + s1;
@@ -80,6 +83,7 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img_b
         const float* a2 = &sRow[2][ry][ox + n];
         float g0 = pc.g[0];
         double b1 = (double)(a0[0] * g0), b2 = 0, b3 = (double)(a1[0] * g0), b4 = 0, b5 = (double)(a2[0] * g0), b6 = 0;
+#pragma unroll
         for (int k = 1; k <= n; k++) {
             float gk = pc.g[k], xgk = pc.xg[k], xxgk = pc.xxg[k];
             double tg = (double)(a0[k] + a0[-k]);
@@ -102,13 +106,15 @@ void launch_blur3_polyexp(const float* img, float* R, int nslices, int H, int W,
 {
     if (nslices <= 0) return;
     dim3 grid((W + PE_TW - 1) / PE_TW, (H + PE_TH - 1) / PE_TH, nslices);
-    hipLaunchKernelGGL(k_polyexp<true>, grid, dim3(256), 0, st, img, R, H, W, pc);
+    if (pc.n == 5) hipLaunchKernelGGL((k_polyexp<true, 5>), grid, dim3(256), 0, st, img, R, H, W, pc);
+    else hipLaunchKernelGGL((k_polyexp<true, 0>), grid, dim3(256), 0, st, img, R, H, W, pc);
 }
 void launch_polyexp(const float* img, float* R, int nslices, int H, int W, const PolyConsts& pc, hipStream_t st)
 {
     if (nslices <= 0) return;
     dim3 grid((W + PE_TW - 1) / PE_TW, (H + PE_TH - 1) / PE_TH, nslices);
-    hipLaunchKernelGGL(k_polyexp<false>, grid, dim3(256), 0, st, img, R, H, W, pc);
+    if (pc.n == 5) hipLaunchKernelGGL((k_polyexp<false, 5>), grid, dim3(256), 0, st, img, R, H, W, pc);
+    else hipLaunchKernelGGL((k_polyexp<false, 0>), grid, dim3(256), 0, st, img, R, H, W, pc);
 }
 
 __global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict__ Rstack, const float* __restrict__ flow_base,
