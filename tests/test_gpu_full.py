@@ -198,3 +198,18 @@ def test_wide_kernel_on_a_gib_volume_spot_parity(fdn, oracle):
         torch.cuda.empty_cache()
     want = oracle.filter_axis_range(sub, 0, k, 0, 5, mean, 16, 17, nthreads=16)
     assert np.array_equal(got, want[16])
+
+
+def test_non_finite_voxels_do_not_derail_the_kernels(fdn):
+    """A NaN and an Inf voxel (dead detector pixels happen): every gather / remap index is clamped, so the
+    sweep completes, and the damage stays in the columns the running sums carry it down (OpenCV's box
+    filter does the same): columns far from both voxels stay finite."""
+    vol = _vol((12, 64, 160), seed=5)
+    vol[5, 20, 30] = np.nan
+    vol[6, 40, 100] = np.inf
+    k = fdn.get_gaussian_kernel(1.0)
+    for l in (0, 1):
+        out = fdn.OF_filter_along_Z(vol, k, l, 5, np.float32(100.0))
+        assert out.shape == vol.shape and out.dtype == np.float32
+        assert np.isfinite(out[:, :, 56:76]).all()
+        assert not np.isfinite(out[5, 20:, 28:33]).all()
