@@ -100,7 +100,12 @@ def _run_sharded(args, vol, kernels, l, w):
     h.set_stream(torch.cuda.current_stream().cuda_stream)
     border = _lib.BORDER_WRAP if args.compat == "par" else _lib.BORDER_MEAN_PAD
     params = _params(l, w, use_of=not args.no_OF, border_mode=border, chained=not args.recompute_flow)
-    mean = np.asarray(vol, dtype=np.float32).mean()   # seq:420 on the whole volume, numpy's own value
+    # seq:420 on the whole volume, numpy's own value: rank 0 computes it, everyone gets its bits
+    mt = torch.zeros(1, dtype=torch.float32, device=dev)
+    if rank == 0:
+        mt[0] = float(np.asarray(vol, dtype=np.float32).mean())
+    dist.broadcast(mt, src=0)
+    mean = np.float32(mt.item())
     out = SlabEngine(plan, h, dist).filter_3d(slab, kernels, params, mean=mean)
     parts = [torch.empty((e - s,) + tuple(vol.shape[1:]), dtype=torch.float32, device=dev) for s, e in plan.parts[0]]
     for r, g in enumerate(parts):   # slabs may differ in length: one broadcast per owner
