@@ -1,0 +1,30 @@
+"""Determinism soak: the same sweep run repeatedly (and under each occupancy build) must give identical bits --
+a race in the LDS hand-over or the window refill would show up here."""
+import os, sys, subprocess, numpy as np
+sys.path.insert(0, ".")
+code = r'''
+import sys, numpy as np
+sys.path.insert(0, ".")
+import flowdenoising_amd as fd
+from flowdenoising_amd.synth import make_volume
+vol = make_volume((48, 1024, 1024), seed=77, amplitude=100.0)
+k = fd.get_gaussian_kernel(2.0)
+ref = None
+for it in range(6):
+    out = fd.OF_filter_along_Z(vol, k, int(sys.argv[1]), 5, vol.mean())
+    if ref is None: ref = out
+    assert np.array_equal(ref, out), ("run", it)
+np.save(sys.argv[2], ref)
+print("ok", sys.argv[1:], flush=True)
+'''
+outs = []
+for l in (0, 3):
+    for occ in ("3", "4", "5"):
+        fn = f"/tmp/soak_{l}_{occ}.npy"
+        env = dict(os.environ, FDN_FUSED_OCC=occ)
+        subprocess.run([sys.executable, "-c", code, str(l), fn], env=env, check=True)
+        outs.append((l, fn))
+for l in (0, 3):
+    a = [np.load(fn) for ll, fn in outs if ll == l]
+    assert all(np.array_equal(a[0], b) for b in a[1:]), l
+print("all runs and builds bit-identical")
