@@ -237,3 +237,36 @@ def test_errors_are_loud(fdn):
     vol = _vol((4, 34, 36))
     with pytest.raises(FlowdnError):
         fdn.OF_filter(vol, [np.array([0.5, 0.5]), None, None], 0, 5)  # even kernel (seq:93 assert)
+
+
+def _random_cases(n, seed):
+    """Reproducible random sweep configurations: odd shapes (images from 2 pixels up, not multiples of
+    the kernels' 52-column bands), every window half-width the kernels distinguish, pyramid levels,
+    both volume-end conventions, chained and recomputed flow."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(n):
+        axis = int(rng.integers(0, 3))
+        shape = [int(rng.integers(2, 14)), int(rng.integers(2, 90)), int(rng.integers(2, 140))]
+        if i % 5 == 0:                    # some larger images so that pyramids have levels to keep
+            shape[1], shape[2] = int(rng.integers(64, 150)), int(rng.integers(64, 230))
+        img = [s for a, s in enumerate(shape) if a != axis]
+        if min(img) < 2:
+            continue
+        w = int(rng.choice([3, 4, 5, 5, 5, 6, 7, 9, 15]))
+        l = int(rng.integers(0, 4))
+        sigma = float(rng.choice([0.5, 1.0, 1.5, 2.0]))
+        cases.append((tuple(shape), axis, l, w, sigma, int(rng.integers(0, 2)), bool(rng.integers(0, 2)), 1000 + i))
+    return cases
+
+
+@pytest.mark.parametrize("shape,axis,l,w,sigma,border,chained,seed", _random_cases(40, 20261003))
+def test_randomised_sweeps(fdn, oracle, shape, axis, l, w, sigma, border, chained, seed):
+    """Bit-level agreement with the (OpenCV-order) oracle over random shapes and parameters."""
+    vol = _vol(shape, seed=seed)
+    k = fdn.get_gaussian_kernel(sigma)
+    mean = vol.mean()
+    fn = [fdn.OF_filter_along_Z, fdn.OF_filter_along_Y, fdn.OF_filter_along_X][axis]
+    got = fn(vol, k, l, w, mean, border_mode=border, chained=chained)
+    want = oracle.filter_along_axis(vol, axis, k, l, w, mean, border_mode=border, chained=chained, nthreads=8)
+    assert rel_err(got, want) < TIGHT_TOL, (shape, axis, l, w, sigma, border, chained)
