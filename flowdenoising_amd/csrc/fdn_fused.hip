@@ -1,6 +1,6 @@
 // fdn_fused.hip -- the fast path: one kernel launch = one chain step of the sweep for EVERY
 // target slice of the batch: the whole cv2.calcOpticalFlowFarneback(prev=target,
-// next=neighbour, flow=previous flow, levels=0, iterations=3) (src/flowdenoising_sequential.py:62),
+// next=neighbour, flow=previous flow, one pyramid level, iterations=3; winsize 4-9) (src/flowdenoising_sequential.py:62),
 // the warp of the neighbour (seq:51-57) and the weighted accumulate (seq:107), fused.
 //
 // Decomposition: one 256-thread workgroup = one band of 64 image columns of one (target,
@@ -305,11 +305,17 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
                             s = __shfl(vs[c], src[0], 64);
 #pragma unroll
                             for (int j = 1; j <= 2 * MH; j++) s += j == MH ? vs[c] : __shfl(vs[c], src[j], 64);
-                        } else {      // same five terms in the same order, by lane shifts
-                            static_assert(MH == 2, "the DPP window is written for a 5-wide box");
-                            const double m1 = wave_shr1(vs[c]), m2 = wave_shr1(m1);
-                            const double p1 = wave_shl1(vs[c]), p2 = wave_shl1(p1);
-                            s = m2; s += m1; s += vs[c]; s += p1; s += p2;
+                        } else {      // the same terms in the same order, by lane shifts
+                            double lft[MH], rgt[MH];
+                            lft[0] = wave_shr1(vs[c]); rgt[0] = wave_shl1(vs[c]);
+#pragma unroll
+                            for (int i = 1; i < MH; i++) { lft[i] = wave_shr1(lft[i - 1]); rgt[i] = wave_shl1(rgt[i - 1]); }
+                            s = lft[MH - 1];
+#pragma unroll
+                            for (int i = MH - 2; i >= 0; i--) s += lft[i];
+                            s += vs[c];
+#pragma unroll
+                            for (int i = 0; i < MH; i++) s += rgt[i];
                         }
                         a[c] = s;
                     }
@@ -362,27 +368,33 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
 
 bool fused_supported(int winsize, int iters, int H, int W)
 {
-    // the kernel addresses pixels of one image / flow field by 32-bit byte offsets
-    return winsize / 2 == 2 && iters == 3 && H >= 2 && W >= 2 && H < (1 << 24) && W < (1 << 24) && (size_t)H * W < ((size_t)1 << 29);
+    // window half-widths 2 (winsize 4, 5), 3 (6, 7), 4 (8, 9); the kernel addresses pixels of one image /
+    // flow field by 32-bit byte offsets
+    const int mh = winsize / 2;
+    return mh >= 2 && mh <= 4 && iters == 3 && H >= 2 && W >= 2 && H < (1 << 24) && W < (1 << 24) && (size_t)H * W < ((size_t)1 << 29);
 }
 
-// One build of the kernel per occupancy: LDS window size, unroll and VGPR budget chosen for OCC
-// workgroups per CU.  (ms per launch of 512 targets of 1024 x 1024 = 10240 workgroups on MI355X.)
-template <int OCC> struct FusedVariant;
-template <> struct FusedVariant<3> { static constexpr int D = 8, DX = 8, U = 3; };   // 47.0 KB [18.1]
-template <> struct FusedVariant<4> { static constexpr int D = 7, DX = 5, U = 3; };   // 40.2 KB [17.2]
-template <> struct FusedVariant<5> { static constexpr int D = 4, DX = 5, U = 1; };   // 31.4 KB, 96 VGPRs [18.0]
+// One build of the kernel per window half-width MH and occupancy OCC: LDS window size, unroll and VGPR
+// budget chosen for OCC workgroups per CU.  (ms per launch of 512 targets of 1024 x 1024 on MI355X.)
+template <int MH, int OCC> struct FusedVariant;
+template <> struct FusedVariant<2, 3> { static constexpr int D = 8, DX = 8, U = 3; };   // 47.0 KB [18.1]
+template <> struct FusedVariant<2, 4> { static constexpr int D = 7, DX = 5, U = 3; };   // 40.2 KB [17.2]
+template <> struct FusedVariant<2, 5> { static constexpr int D = 4, DX = 5, U = 1; };   // 31.4 KB, 96 VGPRs [18.0]
+template <> struct FusedVariant<3, 4> { static constexpr int D = 6, DX = 5, U = 2; };   // 46 useful columns per band
+template <> struct FusedVariant<4, 3> { static constexpr int D = 7, DX = 6, U = 2; };   // 40 useful columns per band
 
-template <int OCC>
+template <int MH, int OCC>
 static void launch_variant(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
-                           PairBatch pb, int H, int W, double scale, double weight, int nbands, long blocks, FlowSource fs, hipStream_t st)
+                           PairBatch pb, int H, int W, double scale, double weight, FlowSource fs, hipStream_t st)
 {
-    constexpr int MH = 2, D = FusedVariant<OCC>::D, DX = FusedVariant<OCC>::DX, U = FusedVariant<OCC>::U;
+    constexpr int D = FusedVariant<MH, OCC>::D, DX = FusedVariant<MH, OCC>::DX, U = FusedVariant<MH, OCC>::U;
     constexpr int WC = 64 + 2 * DX, WCP = (5 * WC) % 16 == 0 ? WC + 2 : WC;   // as in the kernel
     constexpr unsigned win_bytes = (2 * (MH + 1) + 2 * D + 2) * 5 * WCP * sizeof(float);
     // a CU's 160 KB of LDS is handed out in 2 KB granules
     static_assert(win_bytes + 3 * 2 * 5 * 64 * sizeof(float) <= (160 * 1024 / OCC) / 2048 * 2048, "LDS per workgroup");
-    dim3 grid((unsigned)blocks);
+    const int BW = 64 - 2 * MH * 3;
+    const int nbands = (W + BW - 1) / BW;
+    dim3 grid((unsigned)((long)nbands * pb.npairs));
     static const unsigned lds_pad = getenv("FDN_LDS_PAD") ? (unsigned)atoi(getenv("FDN_LDS_PAD")) : 0u;   // occupancy experiments
     auto launch = [&](auto kern) {
         hipLaunchKernelGGL(kern, grid, dim3(256), win_bytes + lds_pad, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, fs);
@@ -399,8 +411,8 @@ static void launch_variant(const float* Rstack, const float* stack, const float*
     }
 }
 
-// Workgroups per CU for a grid of `blocks` workgroups.  All workgroups of a launch take about the same
-// time, so what counts is the number of rounds: large grids run fastest at 4 per CU [17.2 ms for
+// Workgroups per CU for a grid of `blocks` workgroups (winsize 4-5 builds).  All workgroups of a launch take
+// about the same time, so what counts is the number of rounds: large grids run fastest at 4 per CU [17.2 ms for
 // 10240 workgroups against 18.1 at 3 and 18.0 at 5], but a grid that fits one round at 5 and not at 4
 // -- 1280 workgroups: the 64-slice Z slab of an 8-GPU run -- gains 16 % there [2.69 against 3.21 ms].
 // Measured no better: 5 per CU for 2560 workgroups (2 rounds instead of 3), 3 per CU anywhere.
@@ -425,17 +437,19 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
                             PairBatch pb, int H, int W, int winsize, int iters, double weight, hipStream_t st,
                             int coarse_h, int coarse_w)
 {
-    FlowSource fs{coarse_h, coarse_w, coarse_h > 0 ? (double)coarse_w / W : 1.0, coarse_h > 0 ? (double)coarse_h / H : 1.0};
     if (pb.npairs <= 0) return;
     (void)iters;
-    const int BW = 64 - 2 * 2 * 3;
-    const int nbands = (W + BW - 1) / BW;
-    const long blocks = (long)nbands * pb.npairs;
+    FlowSource fs{coarse_h, coarse_w, coarse_h > 0 ? (double)coarse_w / W : 1.0, coarse_h > 0 ? (double)coarse_h / H : 1.0};
     const double scale = 1. / ((double)winsize * winsize);
+    const int mh = winsize / 2;
+    if (mh == 3) { launch_variant<3, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st); return; }
+    if (mh == 4) { launch_variant<4, 3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st); return; }
+    const int BW = 64 - 2 * 2 * 3;
+    const long blocks = (long)((W + BW - 1) / BW) * pb.npairs;
     switch (choose_occupancy(blocks)) {
-    case 3: launch_variant<3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, blocks, fs, st); break;
-    case 5: launch_variant<5>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, blocks, fs, st); break;
-    default: launch_variant<4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, blocks, fs, st); break;
+    case 3: launch_variant<2, 3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st); break;
+    case 5: launch_variant<2, 5>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st); break;
+    default: launch_variant<2, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st); break;
     }
 }
 

@@ -333,10 +333,18 @@ void launch_update_flow(const float* Rstack, const float* Min, float* Mout, floa
     int rows_per_seg = (H + nseg - 1) / nseg;
     nseg = (H + rows_per_seg - 1) / rows_per_seg;
     dim3 grid((nbands + 3) / 4, nseg, pb.npairs);
-    if (m == 7)        // winsize 15 (BASELINE configs[4]); other widths take the general kernel
-        hipLaunchKernelGGL(k_update_flow_scan_t<7>, grid, dim3(256), 0, st, Rstack, Min, Mout, flow, pb, H, W, scale, nbands, rows_per_seg);
-    else
+    // compile-time window for the usual sizes (winsize 15: BASELINE configs[4]); others take the general kernel
+#define FDN_SCAN_T(MM) hipLaunchKernelGGL(k_update_flow_scan_t<MM>, grid, dim3(256), 0, st, Rstack, Min, Mout, flow, pb, H, W, scale, nbands, rows_per_seg)
+    switch (m) {
+    case 1: FDN_SCAN_T(1); break;
+    case 3: FDN_SCAN_T(3); break;
+    case 4: FDN_SCAN_T(4); break;
+    case 5: FDN_SCAN_T(5); break;
+    case 7: FDN_SCAN_T(7); break;
+    default:
         hipLaunchKernelGGL(k_update_flow_scan, grid, dim3(256), 0, st, Rstack, Min, Mout, flow, pb, H, W, m, scale, nbands, rows_per_seg);
+    }
+#undef FDN_SCAN_T
 }
 
 // ---------------------------------------------------------------------------------

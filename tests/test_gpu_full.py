@@ -123,23 +123,24 @@ def test_kernel_variants_agree_bit_for_bit(fdn, oracle, tmp_path, env):
 
 
 # ---- full-size images (BASELINE.json configs[1] and configs[2]) ---------------------------------
-@pytest.mark.parametrize("axis,shape,levels", [(0, (40, 1024, 1024), 0), (1, (512, 40, 1024), 0), (2, (512, 1024, 40), 0),
-                                               (0, (24, 1024, 1024), 3), (1, (512, 20, 1000), 3)])
-def test_full_size_images_spot_parity(fdn, oracle, axis, shape, levels):
+@pytest.mark.parametrize("axis,shape,levels,w", [(0, (40, 1024, 1024), 0, 5), (1, (512, 40, 1024), 0, 5), (2, (512, 1024, 40), 0, 5),
+                                                 (0, (24, 1024, 1024), 3, 5), (1, (512, 20, 1000), 3, 5),
+                                                 (0, (24, 1024, 1024), 0, 7), (2, (512, 1000, 20), 1, 9)])
+def test_full_size_images_spot_parity(fdn, oracle, axis, shape, levels, w):
     """sigma=2 (K=17) sweeps over full-size images (1024x1024 for Z; 512x1024 for Y and X), without and
     with a 3-level pyramid (par's default): two target slices are compared with the oracle run on the
-    17-slice sub-volume that feeds them."""
+    17-slice sub-volume that feeds them; winsize 7 and 9 exercise the fused kernel's wider-window builds."""
     from flowdenoising_amd.synth import make_volume
     vol = make_volume(shape, seed=1234 + 3, amplitude=100.0)
     k = fdn.get_gaussian_kernel(2.0)
     mean = vol.mean()
     fn = [fdn.OF_filter_along_Z, fdn.OF_filter_along_Y, fdn.OF_filter_along_X][axis]
-    got = fn(vol, k, levels, 5, mean)
+    got = fn(vol, k, levels, w, mean)
     n = shape[axis]
     for t in (3, n // 2):            # one target whose window reaches the mean padding, one interior
         lo, hi = max(0, t - 8), min(n, t + 9)
         sub = np.take(vol, range(lo, hi), axis=axis)
-        want = oracle.filter_axis_range(sub, axis, k, levels, 5, mean, t - lo, t - lo + 1, nthreads=1)
+        want = oracle.filter_axis_range(sub, axis, k, levels, w, mean, t - lo, t - lo + 1, nthreads=1)
         assert rel_err(np.take(got, [t], axis=axis), np.take(want, [t - lo], axis=axis)) < TIGHT_TOL
 
 

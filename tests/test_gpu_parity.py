@@ -270,3 +270,15 @@ def test_randomised_sweeps(fdn, oracle, shape, axis, l, w, sigma, border, chaine
     got = fn(vol, k, l, w, mean, border_mode=border, chained=chained)
     want = oracle.filter_along_axis(vol, axis, k, l, w, mean, border_mode=border, chained=chained, nthreads=8)
     assert rel_err(got, want) < TIGHT_TOL, (shape, axis, l, w, sigma, border, chained)
+
+
+@pytest.mark.parametrize("w", [4, 6, 7, 8, 9])
+@pytest.mark.parametrize("l", [0, 2])
+def test_fused_kernel_window_sizes(fdn, oracle, w, l):
+    """winsize 4-9 (window half-widths 2, 3, 4) run on the fused kernel's builds: multi-band images with
+    interior and edge bands, chains of four steps, with and without pyramid."""
+    vol = _vol((7, 130, 300), seed=31 + w)
+    k = fdn.get_gaussian_kernel(1.0)
+    got = fdn.OF_filter(vol, [k, None, k], l, w)
+    want = oracle.OF_filter(vol, [k, None, k], l, w, nthreads=8)
+    assert np.array_equal(got, want), (w, l, rel_err(got, want))
