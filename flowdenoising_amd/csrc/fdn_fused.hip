@@ -368,10 +368,10 @@ __global__ __launch_bounds__(256, OCC) void k_farneback_fused(const float* __res
 
 bool fused_supported(int winsize, int iters, int H, int W)
 {
-    // window half-widths 2 (winsize 4, 5), 3 (6, 7), 4 (8, 9); the kernel addresses pixels of one image /
-    // flow field by 32-bit byte offsets
+    // window half-widths 1 (winsize 2, 3), 2 (4, 5), 3 (6, 7), 4 (8, 9); the kernel addresses pixels of one
+    // image / flow field by 32-bit byte offsets
     const int mh = winsize / 2;
-    return mh >= 2 && mh <= 4 && iters == 3 && H >= 2 && W >= 2 && H < (1 << 24) && W < (1 << 24) && (size_t)H * W < ((size_t)1 << 29);
+    return mh >= 1 && mh <= 4 && iters == 3 && H >= 2 && W >= 2 && H < (1 << 24) && W < (1 << 24) && (size_t)H * W < ((size_t)1 << 29);
 }
 
 // One build of the kernel per window half-width MH and occupancy OCC: LDS window size, unroll and VGPR
@@ -380,6 +380,7 @@ template <int MH, int OCC> struct FusedVariant;
 template <> struct FusedVariant<2, 3> { static constexpr int D = 8, DX = 8, U = 3; };   // 47.0 KB [18.1]
 template <> struct FusedVariant<2, 4> { static constexpr int D = 7, DX = 5, U = 3; };   // 40.2 KB [17.2]
 template <> struct FusedVariant<2, 5> { static constexpr int D = 4, DX = 5, U = 1; };   // 31.4 KB, 96 VGPRs [18.0]
+template <> struct FusedVariant<1, 4> { static constexpr int D = 7, DX = 5, U = 2; };   // 58 useful columns per band
 template <> struct FusedVariant<3, 4> { static constexpr int D = 6, DX = 5, U = 2; };   // 46 useful columns per band
 template <> struct FusedVariant<4, 3> { static constexpr int D = 7, DX = 6, U = 2; };   // 40 useful columns per band
 
@@ -442,6 +443,7 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
     FlowSource fs{coarse_h, coarse_w, coarse_h > 0 ? (double)coarse_w / W : 1.0, coarse_h > 0 ? (double)coarse_h / H : 1.0};
     const double scale = 1. / ((double)winsize * winsize);
     const int mh = winsize / 2;
+    if (mh == 1) { launch_variant<1, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st); return; }
     if (mh == 3) { launch_variant<3, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st); return; }
     if (mh == 4) { launch_variant<4, 3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st); return; }
     const int BW = 64 - 2 * 2 * 3;

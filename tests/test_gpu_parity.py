@@ -272,10 +272,10 @@ def test_randomised_sweeps(fdn, oracle, shape, axis, l, w, sigma, border, chaine
     assert rel_err(got, want) < TIGHT_TOL, (shape, axis, l, w, sigma, border, chained)
 
 
-@pytest.mark.parametrize("w", [4, 6, 7, 8, 9])
+@pytest.mark.parametrize("w", [2, 3, 4, 6, 7, 8, 9])
 @pytest.mark.parametrize("l", [0, 2])
 def test_fused_kernel_window_sizes(fdn, oracle, w, l):
-    """winsize 4-9 (window half-widths 2, 3, 4) run on the fused kernel's builds: multi-band images with
+    """winsize 2-9 (window half-widths 1 to 4) run on the fused kernel's builds: multi-band images with
     interior and edge bands, chains of four steps, with and without pyramid."""
     vol = _vol((7, 130, 300), seed=31 + w)
     k = fdn.get_gaussian_kernel(1.0)
