@@ -381,7 +381,7 @@ template <> struct FusedVariant<2, 3> { static constexpr int D = 8, DX = 8, U = 
 template <> struct FusedVariant<2, 4> { static constexpr int D = 7, DX = 5, U = 3; };   // 40.2 KB [17.2]
 template <> struct FusedVariant<2, 5> { static constexpr int D = 4, DX = 5, U = 1; };   // 31.4 KB, 96 VGPRs [18.0]
 template <> struct FusedVariant<1, 4> { static constexpr int D = 7, DX = 5, U = 2; };   // 58 useful columns per band
-template <> struct FusedVariant<3, 4> { static constexpr int D = 6, DX = 5, U = 2; };   // 46 useful columns per band
+template <> struct FusedVariant<3, 4> { static constexpr int D = 6, DX = 5, U = 4; };   // 46 useful columns per band
 template <> struct FusedVariant<4, 3> { static constexpr int D = 7, DX = 6, U = 2; };   // 40 useful columns per band
 
 template <int MH, int OCC>
