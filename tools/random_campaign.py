@@ -1,0 +1,24 @@
+"""One-off randomised parity campaign: many more random sweep configurations than the test suite holds."""
+import sys, importlib.util, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+spec = importlib.util.spec_from_file_location("tp", "tests/test_gpu_parity.py"); tp = importlib.util.module_from_spec(spec); spec.loader.exec_module(tp)
+import flowdenoising_amd as fdn
+from oracle import oracle
+oracle.build()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+bad = 0; exact = 0
+cases = tp._random_cases(n, int(sys.argv[2]) if len(sys.argv) > 2 else 777)
+for i, (shape, axis, l, w, sigma, border, chained, seed) in enumerate(cases):
+    vol = tp._vol(shape, seed=seed)
+    k = fdn.get_gaussian_kernel(sigma)
+    mean = vol.mean()
+    fn = [fdn.OF_filter_along_Z, fdn.OF_filter_along_Y, fdn.OF_filter_along_X][axis]
+    got = fn(vol, k, l, w, mean, border_mode=border, chained=chained)
+    want = oracle.filter_along_axis(vol, axis, k, l, w, mean, border_mode=border, chained=chained, nthreads=8)
+    if np.array_equal(got, want):
+        exact += 1
+    else:
+        err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+        print("MISMATCH", (shape, axis, l, w, sigma, border, chained, seed), err, flush=True)
+        bad += 1
+print(f"{len(cases)} cases: {exact} bit-identical, {bad} different")
