@@ -33,7 +33,7 @@ EXPORTS = [
     "fdn_set_workspace_limit", "fdn_malloc", "fdn_free", "fdn_memcpy_h2d", "fdn_memcpy_d2h",
     "fdn_memset_f32", "fdn_gaussian_kernel", "fdn_farneback", "fdn_warp",
     "fdn_filter_axis_dev", "fdn_filter_axis", "fdn_filter_3d_dev", "fdn_filter_3d",
-    "fdn_mean_host", "fdn_mean_dev", "fdn_sum_dev", "fdn_sweep_stack_dev", "fdn_permute_dev",
+    "fdn_mean_host", "fdn_mean_dev", "fdn_np_chunk_sums_dev", "fdn_sum_dev", "fdn_sweep_stack_dev", "fdn_permute_dev",
     "fdn_enable_timers", "fdn_get_timers", "fdn_version",
 ]
 
@@ -271,6 +271,13 @@ class Handle:
         m = ctypes.c_float()
         check(self._lib.fdn_mean_dev(self._h, ctypes.c_void_p(d_in), ctypes.c_size_t(int(count)), ctypes.byref(m)))
         return np.float32(m.value)
+
+    def np_chunk_sums_dev(self, d_in, count):
+        """numpy's float32 pairwise sums of the 8192-element chunks of a device array (the last may be partial)."""
+        out = np.empty((int(count) + 8191) // 8192, dtype=np.float32)
+        check(self._lib.fdn_np_chunk_sums_dev(self._h, ctypes.c_void_p(d_in), ctypes.c_size_t(int(count)),
+                                              ctypes.c_void_p(out.ctypes.data)))
+        return out
 
     def sum_dev(self, d_in, count):
         s = ctypes.c_double()

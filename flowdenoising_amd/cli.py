@@ -74,12 +74,10 @@ def _feedback(state):
 
 def _run_single(args, vol, kernels, l, w, device):
     from . import _lib
-    from .operators import _params, handle
+    from .operators import _params, filter_3d_own_mean
     border = _lib.BORDER_WRAP if args.compat == "par" else _lib.BORDER_MEAN_PAD
     params = _params(l, w, use_of=not args.no_OF, border_mode=border, chained=not args.recompute_flow)
-    vol32 = np.ascontiguousarray(vol, dtype=np.float32)
-    mean = vol32.mean()  # seq:420
-    return handle(device).filter_3d(vol32, kernels, mean, params)
+    return filter_3d_own_mean(vol, kernels, params, device)   # mean = vol.mean() (seq:420), taken on the GPU
 
 
 def _run_sharded(args, vol, kernels, l, w):

@@ -898,16 +898,6 @@ FDN_API int fdn_sum_dev(fdn_handle h, const float* d_in, size_t count, double* s
     return 0;
 }
 
-FDN_API int fdn_mean_dev(fdn_handle h, const float* d_in, size_t count, float* mean_out)
-{
-    if (!mean_out) return fail("NULL pointer");
-    if (!count) return fail("empty volume");
-    double s = 0;
-    if (fdn_sum_dev(h, d_in, count, &s)) return -1;
-    *mean_out = (float)(s / (double)count);
-    return 0;
-}
-
 // numpy's float32 add.reduce over a contiguous array (loops.c.src @TYPE@_pairwise_sum): blocks of
 // <= 128 elements are summed with 8 interleaved accumulators, larger ranges split at
 // n/2 rounded down to a multiple of 8.  vol.mean() (seq:420) = f32(sum) / f32(n).
@@ -941,6 +931,46 @@ FDN_API int fdn_mean_host(const float* in, size_t count, float* mean_out)
     // accumulated left to right in float32
     float tot = 0.f;
     for (size_t s = 0; s < count; s += 8192) tot += np_pairwise_sum_f32(in + s, std::min<size_t>(8192, count - s));
+    *mean_out = tot / (float)count;
+    return 0;
+}
+
+// The per-chunk sums of that reduction for a DEVICE array: sums_out[c] (host, ceil(count / 8192) values)
+// = numpy's pairwise sum of chunk c; the last chunk may be partial.
+FDN_API int fdn_np_chunk_sums_dev(fdn_handle h, const float* d_in, size_t count, float* sums_out)
+{
+    FDN_ENTER(h);
+    if (!d_in || !sums_out) return fail("NULL pointer");
+    if (!count) return fail("empty volume");
+    size_t full = count / 8192, rest = count % 8192;
+    if ((uintptr_t)d_in & 15) {       // the kernel reads float4: an unaligned view is reduced on the host
+        std::vector<float> all(count);
+        FDN_HIP(hipMemcpyAsync(all.data(), d_in, count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        FDN_HIP(hipStreamSynchronize(h->stream));
+        for (size_t c = 0; c * 8192 < count; c++) sums_out[c] = np_pairwise_sum_f32(all.data() + c * 8192, std::min<size_t>(8192, count - c * 8192));
+        return 0;
+    }
+    if (full) {
+        if (ensure(h, h->partials, full * sizeof(float))) return -1;
+        launch_np_chunk_sums(d_in, full, (float*)h->partials.p, h->stream);
+        FDN_HIP(hipGetLastError());
+        FDN_HIP(hipMemcpyAsync(sums_out, h->partials.p, full * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    }
+    std::vector<float> tail(rest);
+    if (rest) FDN_HIP(hipMemcpyAsync(tail.data(), d_in + full * 8192, rest * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    FDN_HIP(hipStreamSynchronize(h->stream));
+    if (rest) sums_out[full] = np_pairwise_sum_f32(tail.data(), rest);
+    return 0;
+}
+
+FDN_API int fdn_mean_dev(fdn_handle h, const float* d_in, size_t count, float* mean_out)
+{
+    if (!mean_out) return fail("NULL pointer");
+    if (!count) return fail("empty volume");
+    std::vector<float> sums((count + 8191) / 8192);
+    if (fdn_np_chunk_sums_dev(h, d_in, count, sums.data())) return -1;
+    float tot = 0.f;
+    for (float v : sums) tot += v;     // numpy accumulates its buffered chunks left to right in float32
     *mean_out = tot / (float)count;
     return 0;
 }

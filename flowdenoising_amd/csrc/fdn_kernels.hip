@@ -485,6 +485,35 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
+// numpy's float32 pairwise sum (loops.c.src @TYPE@_pairwise_sum) of every full 8192-element chunk: the
+// recursion halves 8192 down to 64 leaves of 128 elements; a leaf is 8 interleaved accumulators over its
+// 16 groups of 8, combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); leaves combine left + right up the tree.
+// One wave per chunk, one lane per leaf.
+__global__ __launch_bounds__(256) void k_np_chunk_sums(const float* __restrict__ in, size_t nchunks, float* __restrict__ sums)
+{
+    const size_t chunk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (chunk >= nchunks) return;
+    const int lane = threadIdx.x & 63;
+    const float4* a = (const float4*)(in + chunk * 8192 + (size_t)lane * 128);
+    float4 lo = a[0], hi = a[1];
+    float r[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int i = 1; i < 16; i++) {
+        lo = a[2 * i]; hi = a[2 * i + 1];
+        r[0] += lo.x; r[1] += lo.y; r[2] += lo.z; r[3] += lo.w;
+        r[4] += hi.x; r[5] += hi.y; r[6] += hi.z; r[7] += hi.w;
+    }
+    float s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) s = s + __shfl_down(s, d, 64);   // lanes that are multiples of 2d hold valid sums
+    if (lane == 0) sums[chunk] = s;
+}
+void launch_np_chunk_sums(const float* in, size_t nchunks, float* sums, hipStream_t st)
+{
+    if (!nchunks) return;
+    hipLaunchKernelGGL(k_np_chunk_sums, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, st, in, nchunks, sums);
+}
+
 int launch_sum_partials(const float* in, size_t count, double* partials, int max_blocks, hipStream_t st)
 {
     size_t g = (count + 255) / 256;

@@ -95,6 +95,9 @@ class HipBackend:
     def local_sum(self, t):
         return self.h.sum_dev(t.data_ptr(), t.numel())
 
+    def chunk_sums(self, t):
+        return self.h.np_chunk_sums_dev(t.data_ptr(), t.numel())
+
 
 class SlabEngine:
     """Distributed OF_filter / no_OF_filter on Z-slabs.  `dist` is torch.distributed (or None for a
@@ -132,8 +135,26 @@ class SlabEngine:
                     w.wait()
 
     def global_mean(self, vol):
-        """seq:420 for a sharded volume: float64 sum per rank, one scalar all-reduce."""
+        """seq:420 for a sharded volume.  numpy reduces a float32 volume as pairwise sums of 8192-element
+        chunks accumulated left to right in float32; when every slab starts at a chunk boundary (Y*X a
+        multiple of 8192, as for 1024 x 1024 slices) the ranks form their chunks' sums, gather them and
+        accumulate in order: numpy's value exactly.  Otherwise: float64 sum per rank, one scalar
+        all-reduce (within 1 ulp)."""
         torch, dist = self.torch, self.dist
+        Z, Y, X = self.plan.shape
+        if (Y * X) % 8192 == 0 and hasattr(self.backend, "chunk_sums"):
+            mine = np.ascontiguousarray(self.backend.chunk_sums(vol), dtype=np.float32)
+            if dist is not None and self.plan.world > 1:
+                per = [(e - s) * (Y * X // 8192) for s, e in self.plan.parts[0]]
+                buf = torch.zeros(max(per), dtype=torch.float32, device=vol.device)
+                buf[:mine.size] = torch.from_numpy(mine).to(vol.device)
+                got = [torch.empty_like(buf) for _ in range(self.plan.world)]
+                dist.all_gather(got, buf)
+                allsums = np.concatenate([g[:n].cpu().numpy() for g, n in zip(got, per)])
+            else:
+                allsums = mine
+            tot = np.cumsum(allsums, dtype=np.float32)[-1]     # sequential float32 accumulation
+            return np.float32(tot / np.float32(Z * Y * X))
         s = float(self.backend.local_sum(vol))
         if dist is not None and self.plan.world > 1:
             t = torch.tensor([s], dtype=torch.float64, device=vol.device)

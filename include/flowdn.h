@@ -121,10 +121,16 @@ int fdn_filter_3d(fdn_handle h, const float* in, float* out, int Z, int Y, int X
  * pairwise summation).  The padded borders make the result sensitive to the last bit of this
  * value, so use it (or numpy itself) whenever bit-faithfulness to the reference matters. */
 int fdn_mean_host(const float* in, size_t count, float* mean_out);
-/* the same mean of a DEVICE volume, accumulated in float64 and rounded once: at most 1 ulp from
- * numpy's value (used when the volume only exists on the GPU, e.g. across ranks) */
+/* the same mean of a DEVICE volume, equally bit-identical to numpy's: the pairwise sums of the
+ * 8192-element chunks are formed on the GPU in numpy's order, their left-to-right float32
+ * accumulation on the host */
 int fdn_mean_dev(fdn_handle h, const float* d_in, size_t count, float* mean_out);
-/* sum only (float64), for the multi-GPU all-reduce of the mean */
+/* those chunk sums themselves: sums_out (HOST, ceil(count / 8192) floats; the last chunk may be partial).
+ * Ranks whose slabs start at multiples of 8192 elements concatenate them to get numpy's mean of the
+ * whole volume exactly. */
+int fdn_np_chunk_sums_dev(fdn_handle h, const float* d_in, size_t count, float* sums_out);
+/* sum only (float64): the fallback for the multi-GPU mean when slabs do not start at chunk boundaries
+ * (at most 1 ulp from numpy's value) */
 int fdn_sum_dev(fdn_handle h, const float* d_in, size_t count, double* sum_out);
 
 /* ---- slab primitives (multi-GPU decomposition; the reviewer variant

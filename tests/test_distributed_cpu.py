@@ -27,6 +27,10 @@ class OracleBackend:
     def local_sum(self, t):
         return float(t.numpy().astype(np.float64).sum())
 
+    def chunk_sums(self, t):
+        a = t.numpy().reshape(-1)      # numpy's own pairwise sum of each 8192-element chunk
+        return np.array([a[s:s + 8192].sum(dtype=np.float32) for s in range(0, a.size, 8192)], dtype=np.float32)
+
 
 def _free_port():
     with socket.socket() as s:
@@ -92,6 +96,16 @@ def test_sharded_of_filter_equals_single_process(oracle, world, shape):
     want = oracle.OF_filter(vol, [oracle.get_gaussian_kernel(s) for s in sig], 0, 5)
     assert np.array_equal(got, want)
     assert abs(mean_auto - float(vol.mean())) <= 2e-7 * abs(float(vol.mean()))
+
+
+def test_sharded_mean_is_numpys_when_slabs_start_at_chunk_boundaries(oracle):
+    """Y*X a multiple of 8192 (as for 1024 x 1024 slices): the engine's own mean is numpy's float32 mean
+    of the whole volume, bit for bit, and with it the sharded result equals the single-process one."""
+    from flowdenoising_amd.synth import make_volume
+    shape, sig = (7, 64, 128), (1.0, None, None)
+    _, mean_auto = _run(3, shape, sig)
+    vol = make_volume(shape, seed=21, amplitude=100.0)
+    assert np.float32(mean_auto) == vol.mean()
 
 
 def test_sharded_wrap_borders_and_axis_subset(oracle):

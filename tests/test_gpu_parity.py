@@ -282,3 +282,21 @@ def test_fused_kernel_window_sizes(fdn, oracle, w, l):
     got = fdn.OF_filter(vol, [k, None, k], l, w)
     want = oracle.OF_filter(vol, [k, None, k], l, w, nthreads=8)
     assert np.array_equal(got, want), (w, l, rel_err(got, want))
+
+
+@pytest.mark.parametrize("n", [1, 7, 130, 8191, 8192, 8193, 3 * 8192 + 77, 40 * 8192, 64 * 128 * 131])
+def test_device_mean_is_numpys_float32_mean(fdn, n):
+    """vol.mean() (seq:420) on the GPU: numpy's pairwise sums per 8192-element chunk, then its left-to-right
+    float32 accumulation -- the padded volume ends are sensitive to the last bit of this value."""
+    from flowdenoising_amd import _lib
+    from flowdenoising_amd.operators import handle
+    rng = np.random.default_rng(n)
+    a = (rng.standard_normal(n) * 100 + 37).astype(np.float32)
+    h = handle(0)
+    d = h.malloc(a.nbytes)
+    try:
+        h.h2d(d, a)
+        assert h.mean_dev(d, n) == a.mean()
+        assert np.array_equal(h.np_chunk_sums_dev(d, n), [a[s:s + 8192].sum(dtype=np.float32) for s in range(0, n, 8192)])
+    finally:
+        h.free(d)
