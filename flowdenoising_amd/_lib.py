@@ -164,6 +164,9 @@ class Handle:
         assert arr.flags["C_CONTIGUOUS"]
         check(self._lib.fdn_memcpy_d2h(self._h, _ptr(arr), ctypes.c_void_p(dptr), ctypes.c_size_t(arr.nbytes)))
 
+    def memset_f32(self, dptr, value, count):
+        check(self._lib.fdn_memset_f32(self._h, ctypes.c_void_p(dptr), ctypes.c_float(float(value)), ctypes.c_size_t(int(count))))
+
     def enable_timers(self, on=True):
         check(self._lib.fdn_enable_timers(self._h, ctypes.c_int(int(on))))
 

@@ -61,6 +61,9 @@ def build_parser():
     p.add_argument("--compat", choices=("seq", "par"), default="seq",
                    help="seq: flowdenoising_sequential.py semantics (mean-padded ends, levels 0); "
                         "par: flowdenoising.py semantics (wrap-around ends, levels 3, float32 TIFF)")
+    p.add_argument("--chunk_slices", type=int, default=0,
+                   help="Out-of-core mode: keep the volume on the host and process this many slices of a pass at a "
+                        "time on the GPU (-1: as many as fit); for volumes larger than GPU memory")
     p.add_argument("--device", type=int, default=0, help="GPU index")
     p.add_argument("--gpus", type=int, default=1, help="Shard the volume over this many GPUs of the node")
     return p
@@ -77,6 +80,10 @@ def _run_single(args, vol, kernels, l, w, device):
     from .operators import _params, filter_3d_own_mean
     border = _lib.BORDER_WRAP if args.compat == "par" else _lib.BORDER_MEAN_PAD
     params = _params(l, w, use_of=not args.no_OF, border_mode=border, chained=not args.recompute_flow)
+    if args.chunk_slices:
+        from .streaming import filter_streamed
+        return filter_streamed(vol, kernels, l, w, None if args.chunk_slices < 0 else args.chunk_slices,
+                               use_of=not args.no_OF, border_mode=border, chained=not args.recompute_flow, device=device)
     return filter_3d_own_mean(vol, kernels, params, device)   # mean = vol.mean() (seq:420), taken on the GPU
 
 

@@ -214,3 +214,16 @@ def test_non_finite_voxels_do_not_derail_the_kernels(fdn):
         assert out.shape == vol.shape and out.dtype == np.float32
         assert np.isfinite(out[:, :, 56:76]).all()
         assert not np.isfinite(out[5, 20:, 28:33]).all()
+
+
+@pytest.mark.parametrize("l,border,chunk", [(0, 0, 3), (1, 0, 4), (0, 1, 5), (0, 0, None)])
+def test_streamed_filter_equals_resident_filter(fdn, l, border, chunk):
+    """Out-of-core mode (volume on the host, chunks of a pass's slices on the GPU): bit-identical to the
+    resident OF_filter, with mean-padded and wrap-around volume ends, with a pyramid, and for no_OF."""
+    from flowdenoising_amd import streaming
+    vol = _vol((11, 70, 90), seed=17)
+    ks = [fdn.get_gaussian_kernel(1.0), fdn.get_gaussian_kernel(0.5), fdn.get_gaussian_kernel(1.5)]
+    want = fdn.OF_filter(vol, ks, l, 5, border_mode=border)
+    got = streaming.OF_filter_streamed(vol, ks, l, 5, chunk, border_mode=border)
+    assert np.array_equal(got, want)
+    assert np.array_equal(streaming.no_OF_filter_streamed(vol, ks, chunk), fdn.no_OF_filter(vol, ks))
