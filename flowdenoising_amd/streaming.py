@@ -32,9 +32,11 @@ def auto_chunk(shape, axis, halo, free_bytes):
 
 
 def filter_streamed(vol, kernels, l, w, chunk_slices=None, use_of=True, border_mode=_lib.BORDER_MEAN_PAD,
-                    chained=True, device=0, mean=None):
-    """OF_filter / no_OF_filter (seq:419-431) with at most `chunk_slices` target slices of a pass on the GPU
-    (None: as many as fit).  `vol`: (Z, Y, X) array-like on the host; returns a new float32 array."""
+                    chained=True, device=0, mean=None, workers=2):
+    """OF_filter / no_OF_filter (seq:419-431) with at most `chunk_slices` target slices of a pass per worker on
+    the GPU (None: as many as fit).  `workers` chunks are in flight at once, each on its own handle and
+    stream, so that one chunk's host copies and transfers overlap another's kernels.
+    `vol`: (Z, Y, X) array-like on the host; returns a new float32 array."""
     src = np.asarray(vol)
     if src.ndim != 3:
         raise ValueError(f"expected a (Z, Y, X) volume, got shape {src.shape}")
@@ -65,6 +67,29 @@ def filter_streamed(vol, kernels, l, w, chunk_slices=None, use_of=True, border_m
                     h2.free(d_out)
             finally:
                 h2.free(d_in)
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    tls = threading.local()
+    made = []
+
+    def worker_handle():              # one handle (stream, workspaces) per worker thread
+        if not hasattr(tls, "h"):
+            tls.h = _lib.Handle(device)
+            made.append(tls.h)
+        return tls.h
+
+    pool = ThreadPoolExecutor(max_workers=max(1, int(workers)))
+    try:
+        cur = _passes(src, kernels, chunk_slices, None if free is None else free // max(1, int(workers)), mean, wrap, params,
+                      pool, worker_handle)
+    finally:
+        pool.shutdown(wait=True)
+        for hh in made:
+            hh.close()
+    return cur if cur is not src else src.copy()
+
+
+def _passes(src, kernels, chunk_slices, free, mean, wrap, params, pool, worker_handle):
     cur = src
     for axis in (0, 1, 2):
         k = kernels[axis]
@@ -81,8 +106,8 @@ def filter_streamed(vol, kernels, l, w, chunk_slices=None, use_of=True, border_m
             step = auto_chunk(cur.shape, axis, r, free)
         else:
             step = max(1, int(chunk_slices))
-        for s0 in range(0, n, step):
-            s1 = min(n, s0 + step)
+        def chunk_job(s0, s1, cur=cur, out=out, axis=axis, k=k, r=r, n=n, H=H, W=W, HW=HW):
+            h = worker_handle()
             S = s1 - s0
             # source slices of stack positions 0 .. S+2r-1 as runs of consecutive slices (host order)
             if wrap:
@@ -135,8 +160,9 @@ def filter_streamed(vol, kernels, l, w, chunk_slices=None, use_of=True, border_m
                 for d in (d_blk, d_out, d_stack):
                     if d:
                         h.free(d)
+        list(pool.map(lambda se: chunk_job(*se), [(s0, min(n, s0 + step)) for s0 in range(0, n, step)]))
         cur = out
-    return cur if cur is not src else src.copy()
+    return cur
 
 
 def OF_filter_streamed(vol, kernels, l, w, chunk_slices=None, **kw):
