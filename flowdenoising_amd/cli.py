@@ -12,7 +12,8 @@ behaviour: levels = 3 by default, wrap-around volume ends (par:312), float32 TIF
 result is written, as src/flowdenoising_GPU.py:460 does.)
 
 New options: --device N (GPU index), --gpus N (shard over N GPUs of this node; re-launches itself
-under torch.distributed.run).
+under torch.distributed.run), --chunk_slices N (out-of-core mode for volumes larger than the GPU's
+memory: the volume stays on the host, N slices of a pass at a time on the GPU; -1 = as many as fit).
 """
 import argparse
 import hashlib
