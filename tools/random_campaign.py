@@ -6,7 +6,7 @@ import flowdenoising_amd as fdn
 from oracle import oracle
 oracle.build()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
-bad = 0; exact = 0
+bad = 0; exact = 0; order = 0
 cases = tp._random_cases(n, int(sys.argv[2]) if len(sys.argv) > 2 else 777)
 for i, (shape, axis, l, w, sigma, border, chained, seed) in enumerate(cases):
     vol = tp._vol(shape, seed=seed)
@@ -18,7 +18,10 @@ for i, (shape, axis, l, w, sigma, border, chained, seed) in enumerate(cases):
     if np.array_equal(got, want):
         exact += 1
     else:
+        want2 = oracle.filter_along_axis(vol, axis, k, l, w, mean, border_mode=border, chained=chained, box_mode=2, nthreads=8)
         err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
-        print("MISMATCH", (shape, axis, l, w, sigma, border, chained, seed), err, flush=True)
-        bad += 1
-print(f"{len(cases)} cases: {exact} bit-identical, {bad} different")
+        kind = "f64 summation order only" if np.array_equal(got, want2) else "REAL MISMATCH"
+        print(kind, (shape, axis, l, w, sigma, border, chained, seed), err, flush=True)
+        bad += kind == "REAL MISMATCH"
+        order += kind != "REAL MISMATCH"
+print(f"{len(cases)} cases: {exact} bit-identical to the OpenCV-order oracle, {order} differ by f64 summation order only, {bad} real mismatches")

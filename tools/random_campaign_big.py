@@ -7,7 +7,8 @@ from oracle import oracle
 oracle.build()
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-bad = 0
+bad = order = 0
+worst = 0.0
 for i in range(n):
     axis = int(rng.integers(0, 3))
     small, a, b = int(rng.integers(3, 8)), int(rng.integers(100, 420)), int(rng.integers(100, 640))
@@ -21,6 +22,13 @@ for i in range(n):
     got = fn(vol, k, l, w, mean, border_mode=border, chained=chained)
     want = oracle.filter_along_axis(vol, axis, k, l, w, mean, border_mode=border, chained=chained, nthreads=16)
     if not np.array_equal(got, want):
-        bad += 1
-        print("MISMATCH", shape, axis, l, w, sigma, border, chained, np.abs(got - want).max() / np.abs(want).max(), flush=True)
-print(f"{n} cases, {bad} different")
+        # the only designed difference: OpenCV's serial f64 running sum along x against the kernels' direct window sum
+        want2 = oracle.filter_along_axis(vol, axis, k, l, w, mean, border_mode=border, chained=chained, box_mode=2, nthreads=16)
+        err = np.abs(got - want).max() / np.abs(want).max()
+        kind = "f64 summation order only" if np.array_equal(got, want2) else "REAL MISMATCH"
+        bad += kind == "REAL MISMATCH"
+        order += kind != "REAL MISMATCH"
+        worst = max(worst, err)
+        print(kind, shape, axis, l, w, sigma, border, chained, err, flush=True)
+print(f"{n} cases: {n - bad - order} bit-identical to the OpenCV-order oracle, {order} differ by f64 summation order only "
+      f"(worst {worst:.2e} relative; bit-identical to the kernel-order oracle), {bad} real mismatches")
