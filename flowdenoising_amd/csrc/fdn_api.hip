@@ -359,7 +359,9 @@ static void run_iterations(fdn_ctx* h, const float* Rstack, float* flow, float* 
     for (int it = 0; it < iters; it++) {
         bool update = it < iters - 1;
         ScopedTimer t(h, FDN_TIMER_UPDATE_FLOW);
-        launch_update_flow(Rstack, cur, update ? nxt : nullptr, flow, pb, H, W, winsize, h->stream);
+        static const bool strict = getenv("FDN_STRICT_ORDER") && atoi(getenv("FDN_STRICT_ORDER"));
+        if (!(strict && launch_update_flow_strict(Rstack, cur, update ? nxt : nullptr, flow, pb, H, W, winsize, h->stream)))
+            launch_update_flow(Rstack, cur, update ? nxt : nullptr, flow, pb, H, W, winsize, h->stream);
         std::swap(cur, nxt);
     }
 }
@@ -460,7 +462,8 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
         launch_blur3_polyexp(stack, (float*)h->R.p, nstack, H, W, pc, st);
     }
     if (pyramid && build_R_pyramid(h, stack, nstack, H, W, lv, pc)) return -1;
-    bool fused = fused_supported(p->winsize, p->iters, H, W) && !getenv("FDN_FORCE_STAGED");
+    bool fused = fused_supported(p->winsize, p->iters, H, W) && !getenv("FDN_FORCE_STAGED") &&
+                 !(getenv("FDN_STRICT_ORDER") && atoi(getenv("FDN_STRICT_ORDER")));
     for (size_t k = 1; k < lv.size(); k++) fused = fused && fused_supported(p->winsize, p->iters, lv[k].h, lv[k].w);
     // targets per batch, bounded by the workspace limit.  fused: two flow buffers (16 B/px), with a
     // pyramid two more per coarser level;

@@ -48,6 +48,9 @@ struct PairBatch {
 void launch_update_matrices(const float* Rstack, const float* flow, float* M, PairBatch pb,
                             int H, int W, hipStream_t st);
 // flow[b] = solve(box_w(Min[b])); if Mout: Mout[b] = UpdateMatrices(R[t], R[n], flow[b])
+// the same with OpenCV's serial horizontal running sum (FDN_STRICT_ORDER=1); false: row too wide for the LDS
+bool launch_update_flow_strict(const float* Rstack, const float* Min, float* Mout, float* flow, PairBatch pb,
+                               int H, int W, int winsize, hipStream_t st);
 void launch_update_flow(const float* Rstack, const float* Min, float* Mout, float* flow,
                         PairBatch pb, int H, int W, int winsize, hipStream_t st);
 // acc[b] = f32( f64(acc[b]) + f64(remap(stack[n], flow[b])) * weight )

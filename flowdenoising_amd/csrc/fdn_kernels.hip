@@ -315,6 +315,92 @@ __global__ __launch_bounds__(256) void k_update_flow_scan_t(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Strict mode (FDN_STRICT_ORDER=1): FarnebackUpdateFlow_Blur with OpenCV's HORIZONTAL running sum
+// too -- g += vsum[x+m] - vsum[x-m-1], one serial f64 chain along each row -- instead of the
+// window summed directly.  The two differ by f64 rounding only (~1e-16), which the near-singular
+// solve can turn into a different f32 flow once in ~10^10 pixels; this kernel exists to show that
+// this is the only difference: with it the GPU reproduces the OpenCV-order oracle bit for bit.
+// One workgroup per pair marches down the rows: all threads update the row's vertical running sums
+// in LDS, five threads (one per channel) walk the row serially, all threads solve.  Slow by design.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_update_flow_strict(const float* __restrict__ Rstack, const float* __restrict__ Min_base,
+                                                            float* __restrict__ Mout_base, float* __restrict__ flow_base,
+                                                            PairBatch pb, int H, int W, int m, double scale)
+{
+    extern __shared__ double sh[];
+    const int P = W + 2 * (m + 1);               // a row of vsum with m+1 replicated entries either side
+    double* vs = sh;                              // [5][P], entry x + m + 1 = column x
+    double* G = sh + 5 * (size_t)P;               // [5][W]
+    const size_t HW = (size_t)H * W;
+    const int b = blockIdx.x;
+    const float* Mp = Min_base + (size_t)b * 5 * HW;
+    const RImage R0 = r_image(Rstack + (size_t)(pb.t0 + b) * 5 * HW, HW);
+    const RImage R1 = r_image(Rstack + (size_t)(pb.t0 + b + pb.d) * 5 * HW, HW);
+    float2* flow = (float2*)flow_base + (size_t)b * HW;
+    float* Mout = Mout_base ? Mout_base + (size_t)b * 5 * HW : nullptr;
+
+    for (int x = threadIdx.x; x < W; x += 256) {
+        double v[5];
+        vsum_init(Mp, HW, H, W, x, m, v);
+#pragma unroll
+        for (int c = 0; c < 5; c++) vs[c * P + x + m + 1] = v[c];
+    }
+    __syncthreads();
+    for (int y = 0; y < H; y++) {
+        const float* p1 = Mp + (size_t)(y + m < H - 1 ? y + m : H - 1) * W;
+        const float* p0 = Mp + (size_t)(y - m - 1 > 0 ? y - m - 1 : 0) * W;
+        for (int x = threadIdx.x; x < W; x += 256) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) vs[c * P + x + m + 1] += (double)(p1[c * HW + x] - p0[c * HW + x]);
+        }
+        __syncthreads();
+        if (threadIdx.x < 5) {                    // the serial chain of one channel
+            double* v = vs + threadIdx.x * P + m + 1;
+            for (int k = 1; k <= m + 1; k++) { v[-k] = v[0]; v[W - 1 + k] = v[W - 1]; }
+            double g = v[0] * (double)(m + 2);
+            for (int x = 1; x < m; x++) g += v[x];
+            double* out = G + threadIdx.x * (size_t)W;
+            for (int x = 0; x < W; x++) {
+                g += v[x + m] - v[x - m - 1];
+                out[x] = g;
+            }
+        }
+        __syncthreads();
+        for (int x = threadIdx.x; x < W; x += 256) {
+            double a[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) a[c] = G[c * (size_t)W + x];
+            const float2 f = solve_flow(a, scale);
+            const size_t o = (size_t)y * W + x;
+            flow[o] = f;
+            if (Mout) {
+                float mm[5];
+                compute_M(R0, R1, H, W, x, y, f.x, f.y, mm);
+#pragma unroll
+                for (int c = 0; c < 5; c++) Mout[c * HW + o] = mm[c];
+            }
+        }
+        // the next row's vsum update is fenced from this row's chain by the barrier above; its chain from
+        // this row's solve by the barrier after that update
+    }
+}
+
+// returns false when the row does not fit the LDS (caller falls back)
+bool launch_update_flow_strict(const float* Rstack, const float* Min, float* Mout, float* flow, PairBatch pb,
+                               int H, int W, int winsize, hipStream_t st)
+{
+    if (pb.npairs <= 0) return true;
+    const int m = winsize / 2;
+    const size_t bytes = (5 * (size_t)(W + 2 * (m + 1)) + 5 * (size_t)W) * sizeof(double);
+    if (bytes > 160 * 1024) return false;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_update_flow_strict, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    const double scale = 1. / ((double)winsize * winsize);
+    hipLaunchKernelGGL(k_update_flow_strict, dim3(pb.npairs), dim3(256), bytes, st, Rstack, Min, Mout, flow, pb, H, W, m, scale);
+    return true;
+}
+
 void launch_update_flow(const float* Rstack, const float* Min, float* Mout, float* flow, PairBatch pb,
                         int H, int W, int winsize, hipStream_t st)
 {
