@@ -13,7 +13,8 @@ result is written, as src/flowdenoising_GPU.py:460 does.)
 
 New options: --device N (GPU index), --gpus N (shard over N GPUs of this node; re-launches itself
 under torch.distributed.run), --chunk_slices N (out-of-core mode for volumes larger than the GPU's
-memory: the volume stays on the host, N slices of a pass at a time on the GPU; -1 = as many as fit).
+memory: the volume stays on the host, N slices of a pass at a time on the GPU; -1 = as many as fit),
+--strict_order (OpenCV's own f64 summation order in the box filter; slow, for verification).
 """
 import argparse
 import hashlib
@@ -65,6 +66,9 @@ def build_parser():
     p.add_argument("--chunk_slices", type=int, default=0,
                    help="Out-of-core mode: keep the volume on the host and process this many slices of a pass at a "
                         "time on the GPU (-1: as many as fit); for volumes larger than GPU memory")
+    p.add_argument("--strict_order", action="store_true",
+                   help="Run OpenCV's serial horizontal running sum in the box filter instead of the direct window sum "
+                        "(the one f64 summation order in which the fast kernels differ from OpenCV, ~1e-16; about 20x slower)")
     p.add_argument("--device", type=int, default=0, help="GPU index")
     p.add_argument("--gpus", type=int, default=1, help="Shard the volume over this many GPUs of the node")
     return p
@@ -127,6 +131,9 @@ def _run_sharded(args, vol, kernels, l, w):
 def main(argv=None):
     parser = build_parser()
     args = parser.parse_args(argv)
+
+    if args.strict_order:
+        os.environ["FDN_STRICT_ORDER"] = "1"   # read by libflowdn.so on its first sweep
 
     if args.show_fingerprint:  # par:425-431 hashes the script; here: the library that does the work
         from . import _lib
