@@ -30,7 +30,7 @@ class SweepParams(ctypes.Structure):
 # every symbol include/flowdn.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "fdn_create", "fdn_destroy", "fdn_last_error", "fdn_set_stream", "fdn_reset_stream", "fdn_synchronize",
-    "fdn_set_workspace_limit", "fdn_malloc", "fdn_free", "fdn_memcpy_h2d", "fdn_memcpy_d2h",
+    "fdn_set_workspace_limit", "fdn_set_option", "fdn_malloc", "fdn_free", "fdn_memcpy_h2d", "fdn_memcpy_d2h",
     "fdn_memset_f32", "fdn_gaussian_kernel", "fdn_farneback", "fdn_warp",
     "fdn_filter_axis_dev", "fdn_filter_axis", "fdn_filter_3d_dev", "fdn_filter_3d",
     "fdn_mean_host", "fdn_mean_dev", "fdn_np_chunk_sums_dev", "fdn_sum_dev", "fdn_sweep_stack_dev", "fdn_permute_dev",
@@ -147,6 +147,10 @@ class Handle:
 
     def set_workspace_limit(self, nbytes):
         check(self._lib.fdn_set_workspace_limit(self._h, ctypes.c_size_t(int(nbytes))))
+
+    def set_option(self, name, value):
+        """fdn_set_option: "strict_order", "path", "fused_occ", "lds_pad" (see include/flowdn.h)."""
+        check(self._lib.fdn_set_option(self._h, ctypes.c_char_p(name.encode()), ctypes.c_long(int(value))))
 
     def malloc(self, nbytes):
         p = ctypes.c_void_p()

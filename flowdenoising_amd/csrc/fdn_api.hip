@@ -151,6 +151,7 @@ struct fdn_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     size_t ws_limit = 0;
+    Tuning tn;
     DevBuf R, M0, M1, flow, stack, sweep_out, vol_a, vol_b, partials, pair;
     DevBuf Rpyr, flow_pyr, pyr_tmp, area_tab;   // pyramid levels >= 1
     struct AreaKey { int sh, sw, dh, dw; } area_key = {0, 0, 0, 0};
@@ -348,9 +349,12 @@ static int build_R_pyramid(fdn_ctx* h, const float* imgs, int nimg, int H, int W
 
 // Farneback level-0 iterations for a batch of pairs whose R planes are in Rstack and whose
 // flows (initial -> final) are in `flow`; M0/M1 are ping-pong scratch for npairs.
-static void run_iterations(fdn_ctx* h, const float* Rstack, float* flow, float* M0, float* M1, PairBatch pb,
-                           int H, int W, int winsize, int iters)
+static int run_iterations(fdn_ctx* h, const float* Rstack, float* flow, float* M0, float* M1, PairBatch pb,
+                          int H, int W, int winsize, int iters)
 {
+    if (h->tn.strict_order && !strict_order_supported(W, winsize))
+        return fail("strict order was requested, but a row of %d columns (winsize %d) does not fit the 160 KB of LDS "
+                    "its serial running sum needs; strict mode never falls back silently", W, winsize);
     {
         ScopedTimer t(h, FDN_TIMER_UPDATE_MATRICES);
         launch_update_matrices(Rstack, flow, M0, pb, H, W, h->stream);
@@ -359,11 +363,14 @@ static void run_iterations(fdn_ctx* h, const float* Rstack, float* flow, float* 
     for (int it = 0; it < iters; it++) {
         bool update = it < iters - 1;
         ScopedTimer t(h, FDN_TIMER_UPDATE_FLOW);
-        static const bool strict = getenv("FDN_STRICT_ORDER") && atoi(getenv("FDN_STRICT_ORDER"));
-        if (!(strict && launch_update_flow_strict(Rstack, cur, update ? nxt : nullptr, flow, pb, H, W, winsize, h->stream)))
+        if (h->tn.strict_order) {
+            if (!launch_update_flow_strict(Rstack, cur, update ? nxt : nullptr, flow, pb, H, W, winsize, h->stream))
+                return fail("strict order: the serial running-sum kernel could not be launched for rows of %d columns", W);
+        } else
             launch_update_flow(Rstack, cur, update ? nxt : nullptr, flow, pb, H, W, winsize, h->stream);
         std::swap(cur, nxt);
     }
+    return 0;
 }
 
 // All levels of calc() for a batch of pairs: coarsest flow = INTER_AREA shrink of the initial flow
@@ -386,7 +393,7 @@ static int pyramid_batch(fdn_ctx* h, const std::vector<PyrLevel>& lv, const floa
         if (k < L)
             if (resize_dev(h, fp + lv[k + 1].f_off, lv[k + 1].h, lv[k + 1].w, cur, lv[k].h, lv[k].w, 2, n, 1, true, 2.0)) return -1;
         const float* Rk = k == 0 ? R0 : (const float*)h->Rpyr.p + lv[k].r_off;
-        run_iterations(h, Rk, cur, M0, M1, pb, lv[k].h, lv[k].w, winsize, iters);
+        if (run_iterations(h, Rk, cur, M0, M1, pb, lv[k].h, lv[k].w, winsize, iters)) return -1;
     }
     return 0;
 }
@@ -422,11 +429,11 @@ static int pyramid_step_fused(fdn_ctx* h, const std::vector<PyrLevel>& lv, const
         float* b = fp + lv[k].f_off + (size_t)n * lv[k].h * lv[k].w * 2;
         ScopedTimer t(h, FDN_TIMER_FUSED);
         launch_farneback_fused((const float*)h->Rpyr.p + lv[k].r_off, nullptr, fin, b, nullptr, pb, lv[k].h, lv[k].w,
-                               winsize, iters, 0.0, h->stream, ch, cw);
+                               winsize, iters, 0.0, h->stream, h->tn, ch, cw);
         fin = b; ch = lv[k].h; cw = lv[k].w;
     }
     ScopedTimer t(h, FDN_TIMER_FUSED);
-    launch_farneback_fused(R0, stack, fin, out0, acc, pb, H, W, winsize, iters, weight, h->stream, ch, cw);
+    launch_farneback_fused(R0, stack, fin, out0, acc, pb, H, W, winsize, iters, weight, h->stream, h->tn, ch, cw);
     return 0;
 }
 
@@ -462,8 +469,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
         launch_blur3_polyexp(stack, (float*)h->R.p, nstack, H, W, pc, st);
     }
     if (pyramid && build_R_pyramid(h, stack, nstack, H, W, lv, pc)) return -1;
-    bool fused = fused_supported(p->winsize, p->iters, H, W) && !getenv("FDN_FORCE_STAGED") &&
-                 !(getenv("FDN_STRICT_ORDER") && atoi(getenv("FDN_STRICT_ORDER")));
+    bool fused = fused_supported(p->winsize, p->iters, H, W) && h->tn.path == 0 && !h->tn.strict_order;
     for (size_t k = 1; k < lv.size(); k++) fused = fused && fused_supported(p->winsize, p->iters, lv[k].h, lv[k].w);
     // targets per batch, bounded by the workspace limit.  fused: two flow buffers (16 B/px), with a
     // pyramid two more per coarser level;
@@ -511,7 +517,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
                     }
                     ScopedTimer t(h, FDN_TIMER_FUSED);
                     launch_farneback_fused(R, stack, fin, keep ? fout : nullptr, acc, PairBatch{n, r + c0, d}, H, W,
-                                           p->winsize, p->iters, kernel[r + d], st);
+                                           p->winsize, p->iters, kernel[r + d], st, h->tn);
                     if (keep) { fin = fout; fout = fout == flow ? flowB : flow; }
                 }
                 continue;
@@ -523,8 +529,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
                 if (!p->chained && step > 0) launch_fill(flow, 0.f, (size_t)n * HW * 2, st);
                 if (pyramid) {
                     if (pyramid_batch(h, lv, R, flow, M0, M1, pb, H, W, p->winsize, p->iters, p->chained && step > 0)) return -1;
-                } else
-                    run_iterations(h, R, flow, M0, M1, pb, H, W, p->winsize, p->iters);
+                } else if (run_iterations(h, R, flow, M0, M1, pb, H, W, p->winsize, p->iters)) return -1;
                 {
                     ScopedTimer t(h, FDN_TIMER_WARP);
                     launch_warp_accumulate(stack, flow, acc, pb, H, W, kernel[r + d], st);
@@ -620,6 +625,33 @@ static int filter_3d_dev(fdn_ctx* h, const float* d_in, float* d_out, int Z, int
     return 0;
 }
 
+// numpy's add.reduce over a contiguous array (loops.c.src @TYPE@_pairwise_sum): blocks of <= 128 elements
+// are summed with 8 interleaved accumulators, larger ranges split at n/2 rounded down to a multiple of 8.
+// float: vol.mean() (seq:420) = f32(sum) / f32(n); double: the normalisation of the Gaussian taps (seq:37,
+// scipy's phi_x.sum()).
+template <typename T> static T np_pairwise_sum(const T* a, size_t n)
+{
+    if (n < 8) {
+        T res = 0;
+        for (size_t i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        T r[8];
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        size_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    size_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+static float np_pairwise_sum_f32(const float* a, size_t n) { return np_pairwise_sum<float>(a, n); }
+
 // ---- exported C ABI ---------------------------------------------------------------
 extern "C" {
 
@@ -640,6 +672,14 @@ FDN_API int fdn_create(int device, fdn_handle* out)
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
     h->stream = h->own_stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->tn.cus = prop.multiProcessorCount;
+    // the environment is read here, once per handle; fdn_set_option changes a live handle
+    auto env_int = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; };
+    h->tn.strict_order = env_int("FDN_STRICT_ORDER") != 0;
+    h->tn.path = env_int("FDN_FORCE_STAGED") ? 1 : env_int("FDN_PATH");
+    h->tn.fused_occ = env_int("FDN_FUSED_OCC");
+    h->tn.lds_pad = (unsigned)env_int("FDN_LDS_PAD");
     *out = h;
     return 0;
 }
@@ -689,6 +729,18 @@ FDN_API int fdn_set_workspace_limit(fdn_handle h, size_t bytes)
     h->ws_limit = bytes;
     return 0;
 }
+FDN_API int fdn_set_option(fdn_handle h, const char* name, long value)
+{
+    FDN_ENTER(h);
+    if (!name) return fail("option name is NULL");
+    FDN_HIP(hipStreamSynchronize(h->stream));
+    if (!strcmp(name, "strict_order")) h->tn.strict_order = value != 0;
+    else if (!strcmp(name, "path")) { if (value < 0 || value > 2) return fail("path must be 0 (auto), 1 (staged) or 2 (per-iteration kernels)"); h->tn.path = (int)value; }
+    else if (!strcmp(name, "fused_occ")) { if (value && (value < 3 || value > 5)) return fail("fused_occ must be 0, 3, 4 or 5"); h->tn.fused_occ = (int)value; }
+    else if (!strcmp(name, "lds_pad")) { if (value < 0 || value > 160 * 1024) return fail("lds_pad out of range"); h->tn.lds_pad = (unsigned)value; }
+    else return fail("unknown option '%s' (strict_order, path, fused_occ, lds_pad)", name);
+    return 0;
+}
 FDN_API int fdn_malloc(fdn_handle h, size_t bytes, void** dptr)
 {
     FDN_ENTER(h);
@@ -734,8 +786,9 @@ FDN_API int fdn_gaussian_kernel(double sigma, double* out, int cap)
     int r = (int)(4.0 * sigma + 0.5);
     int K = 2 * r + 1;
     if (!out || K > cap) return -K;
-    double sigma2 = sigma * sigma, s = 0;
-    for (int j = -r; j <= r; j++) { out[j + r] = exp(-0.5 / sigma2 * (double)(j * j)); s += out[j + r]; }
+    const double sigma2 = sigma * sigma;
+    for (int j = -r; j <= r; j++) out[j + r] = exp(-0.5 / sigma2 * (double)(j * j));
+    const double s = np_pairwise_sum(out, (size_t)K);     // phi_x.sum() of scipy's _gaussian_kernel1d
     for (int i = 0; i < K; i++) out[i] /= s;
     return K;
 }
@@ -780,8 +833,7 @@ FDN_API int fdn_farneback(fdn_handle h, const float* prev, const float* next, fl
         if (build_R_pyramid(h, img, 2, H, W, lv, pc)) return -1;
         if (ensure_flow_pyramid(h, lv, 1)) return -1;
         if (pyramid_batch(h, lv, R, flow, M0, M1, PairBatch{1, 0, 1}, H, W, winsize, iters, (flags & FDN_USE_INITIAL_FLOW) != 0)) return -1;
-    } else
-        run_iterations(h, R, flow, M0, M1, PairBatch{1, 0, 1}, H, W, winsize, iters);
+    } else if (run_iterations(h, R, flow, M0, M1, PairBatch{1, 0, 1}, H, W, winsize, iters)) return -1;
     FDN_HIP(hipGetLastError());
     {
         ScopedTimer t(h, FDN_TIMER_TRANSFER);
@@ -899,31 +951,6 @@ FDN_API int fdn_sum_dev(fdn_handle h, const float* d_in, size_t count, double* s
     for (int i = 0; i < nb; i++) s += host[i];
     *sum_out = s;
     return 0;
-}
-
-// numpy's float32 add.reduce over a contiguous array (loops.c.src @TYPE@_pairwise_sum): blocks of
-// <= 128 elements are summed with 8 interleaved accumulators, larger ranges split at
-// n/2 rounded down to a multiple of 8.  vol.mean() (seq:420) = f32(sum) / f32(n).
-static float np_pairwise_sum_f32(const float* a, size_t n)
-{
-    if (n < 8) {
-        float res = 0.f;
-        for (size_t i = 0; i < n; i++) res += a[i];
-        return res;
-    }
-    if (n <= 128) {
-        float r[8];
-        for (int j = 0; j < 8; j++) r[j] = a[j];
-        size_t i;
-        for (i = 8; i < n - (n % 8); i += 8)
-            for (int j = 0; j < 8; j++) r[j] += a[i + j];
-        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < n; i++) res += a[i];
-        return res;
-    }
-    size_t n2 = n / 2;
-    n2 -= n2 % 8;
-    return np_pairwise_sum_f32(a, n2) + np_pairwise_sum_f32(a + n2, n - n2);
 }
 
 FDN_API int fdn_mean_host(const float* in, size_t count, float* mean_out)

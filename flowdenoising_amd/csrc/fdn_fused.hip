@@ -386,7 +386,7 @@ template <> struct FusedVariant<4, 3> { static constexpr int D = 7, DX = 6, U = 
 
 template <int MH, int OCC>
 static void launch_variant(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
-                           PairBatch pb, int H, int W, double scale, double weight, FlowSource fs, hipStream_t st)
+                           PairBatch pb, int H, int W, double scale, double weight, FlowSource fs, hipStream_t st, unsigned lds_pad)
 {
     constexpr int D = FusedVariant<MH, OCC>::D, DX = FusedVariant<MH, OCC>::DX, U = FusedVariant<MH, OCC>::U;
     constexpr int WC = 64 + 2 * DX, WCP = (5 * WC) % 16 == 0 ? WC + 2 : WC;   // as in the kernel
@@ -396,7 +396,6 @@ static void launch_variant(const float* Rstack, const float* stack, const float*
     const int BW = 64 - 2 * MH * 3;
     const int nbands = (W + BW - 1) / BW;
     dim3 grid((unsigned)((long)nbands * pb.npairs));
-    static const unsigned lds_pad = getenv("FDN_LDS_PAD") ? (unsigned)atoi(getenv("FDN_LDS_PAD")) : 0u;   // occupancy experiments
     auto launch = [&](auto kern) {
         hipLaunchKernelGGL(kern, grid, dim3(256), win_bytes + lds_pad, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, fs);
     };
@@ -417,41 +416,32 @@ static void launch_variant(const float* Rstack, const float* stack, const float*
 // 10240 workgroups against 18.1 at 3 and 18.0 at 5], but a grid that fits one round at 5 and not at 4
 // -- 1280 workgroups: the 64-slice Z slab of an 8-GPU run -- gains 16 % there [2.69 against 3.21 ms].
 // Measured no better: 5 per CU for 2560 workgroups (2 rounds instead of 3), 3 per CU anywhere.
-static int choose_occupancy(long blocks)
+static int choose_occupancy(long blocks, const Tuning& tn)
 {
-    static int forced = -1, cus = 0;
-    if (forced < 0) {
-        const char* e = getenv("FDN_FUSED_OCC");
-        forced = e ? atoi(e) : 0;
-        hipDeviceProp_t prop;
-        int dev = 0;
-        cus = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
-        if (cus <= 0) cus = 256;
-    }
-    if (forced >= 3 && forced <= 5) return forced;
-    return blocks > (long)cus * 4 && blocks <= (long)cus * 5 ? 5 : 4;
+    if (tn.fused_occ >= 3 && tn.fused_occ <= 5) return tn.fused_occ;
+    return blocks > (long)tn.cus * 4 && blocks <= (long)tn.cus * 5 ? 5 : 4;
 }
 
 // acc == nullptr: Farneback only (a coarser pyramid level), flow_out is required then.
 // coarse_h, coarse_w > 0: flow_in holds the next coarser level's flow of that size (upsampled in the kernel).
 void launch_farneback_fused(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
                             PairBatch pb, int H, int W, int winsize, int iters, double weight, hipStream_t st,
-                            int coarse_h, int coarse_w)
+                            const Tuning& tn, int coarse_h, int coarse_w)
 {
     if (pb.npairs <= 0) return;
     (void)iters;
     FlowSource fs{coarse_h, coarse_w, coarse_h > 0 ? (double)coarse_w / W : 1.0, coarse_h > 0 ? (double)coarse_h / H : 1.0};
     const double scale = 1. / ((double)winsize * winsize);
     const int mh = winsize / 2;
-    if (mh == 1) { launch_variant<1, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st); return; }
-    if (mh == 3) { launch_variant<3, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st); return; }
-    if (mh == 4) { launch_variant<4, 3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st); return; }
+    if (mh == 1) { launch_variant<1, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad); return; }
+    if (mh == 3) { launch_variant<3, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad); return; }
+    if (mh == 4) { launch_variant<4, 3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad); return; }
     const int BW = 64 - 2 * 2 * 3;
     const long blocks = (long)((W + BW - 1) / BW) * pb.npairs;
-    switch (choose_occupancy(blocks)) {
-    case 3: launch_variant<2, 3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st); break;
-    case 5: launch_variant<2, 5>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st); break;
-    default: launch_variant<2, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st); break;
+    switch (choose_occupancy(blocks, tn)) {
+    case 3: launch_variant<2, 3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad); break;
+    case 5: launch_variant<2, 5>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad); break;
+    default: launch_variant<2, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad); break;
     }
 }
 

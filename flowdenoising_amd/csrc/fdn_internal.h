@@ -48,7 +48,9 @@ struct PairBatch {
 void launch_update_matrices(const float* Rstack, const float* flow, float* M, PairBatch pb,
                             int H, int W, hipStream_t st);
 // flow[b] = solve(box_w(Min[b])); if Mout: Mout[b] = UpdateMatrices(R[t], R[n], flow[b])
-// the same with OpenCV's serial horizontal running sum (FDN_STRICT_ORDER=1); false: row too wide for the LDS
+// the same with OpenCV's serial horizontal running sum (strict_order); false: a row of W columns does not fit
+// the LDS (strict_order_supported tells beforehand)
+bool strict_order_supported(int W, int winsize);
 bool launch_update_flow_strict(const float* Rstack, const float* Min, float* Mout, float* flow, PairBatch pb,
                                int H, int W, int winsize, hipStream_t st);
 void launch_update_flow(const float* Rstack, const float* Min, float* Mout, float* flow,
@@ -62,6 +64,17 @@ void launch_axpy_slices(const float* stack, float* acc, PairBatch pb, int H, int
 // dst(y,x) = remap(src, flow)  single image (fdn_warp)
 void launch_warp(const float* src, const float* flow, float* dst, int H, int W, hipStream_t st);
 
+// Per-handle switches: read from the environment once, at fdn_create, and changed with fdn_set_option
+// (tests and experiments; every path gives the same bits except strict_order).
+struct Tuning {
+    int strict_order = 0;    // FDN_STRICT_ORDER: OpenCV's serial horizontal running sum in the box filter
+    int path = 0;            // FDN_PATH: 0 = automatic, 1 = staged per-stage kernels (also FDN_FORCE_STAGED=1),
+                             //           2 = one-iteration kernels (k_farneback_iter) whatever the window
+    int fused_occ = 0;       // FDN_FUSED_OCC: pin the 3-iteration fused kernel's occupancy build (3, 4, 5)
+    unsigned lds_pad = 0;    // FDN_LDS_PAD: extra dynamic LDS per workgroup (occupancy curves)
+    int cus = 256;           // compute units of the handle's device
+};
+
 // Fused chain step (fdn_fused.hip): for every pair of the batch, the whole level-0 Farneback
 // (initial matrices + iters x [box filter, solve, refresh]) seeded by flow_in (NULL = zero
 // flow), then acc += weight * remap(stack[n], flow); flow_out (NULL = not needed) receives
@@ -69,7 +82,7 @@ void launch_warp(const float* src, const float* flow, float* dst, int H, int W, 
 bool fused_supported(int winsize, int iters, int H, int W);
 void launch_farneback_fused(const float* Rstack, const float* stack, const float* flow_in, float* flow_out,
                             float* acc, PairBatch pb, int H, int W, int winsize, int iters, double weight,
-                            hipStream_t st, int coarse_h = 0, int coarse_w = 0);
+                            hipStream_t st, const Tuning& tn, int coarse_h = 0, int coarse_w = 0);
 
 // where the fused kernel's initial flow comes from when it is the next coarser pyramid level's result
 struct FlowSource { int h, w; double sx, sy; };   // h == 0: flow_in has the image's own size

@@ -216,7 +216,10 @@ __global__ __launch_bounds__(256) void k_update_flow_scan(const float* __restric
             vs[c] += (double)(p1[c * HW] - p0[c * HW]);
             xch[wv][c][lane] = vs[c];
         }
-        // only this wave reads what it wrote, and a wave's LDS operations execute in order
+        // only this wave reads what it wrote and a wave's LDS operations execute in order; the fences keep the
+        // compiler from moving the reads across the writes (other lanes' addresses), as in k_update_flow_scan_t
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         const int jlo = lane - m < 0 ? 0 : lane - m, jhi = lane + m > 63 ? 63 : lane + m;
 #pragma unroll
         for (int c = 0; c < 5; c++) {
@@ -227,6 +230,8 @@ __global__ __launch_bounds__(256) void k_update_flow_scan(const float* __restric
             for (int j = jhi + 1; j <= lane + m; j++) s += xch[wv][c][63]; // and right of it
             a[c] = s;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // next row's writes stay behind these reads
+        __builtin_amdgcn_wave_barrier();
         if (owner) {
             float2 f = solve_flow(a, scale);
             size_t o = (size_t)y * W + x;
@@ -386,16 +391,23 @@ __global__ __launch_bounds__(256) void k_update_flow_strict(const float* __restr
     }
 }
 
-// returns false when the row does not fit the LDS (caller falls back)
+static size_t strict_lds_bytes(int W, int winsize)
+{
+    const int m = winsize / 2;
+    return (5 * (size_t)(W + 2 * (m + 1)) + 5 * (size_t)W) * sizeof(double);
+}
+bool strict_order_supported(int W, int winsize) { return strict_lds_bytes(W, winsize) <= 160 * 1024; }
+
+// returns false when the row does not fit the LDS (the caller reports the error: strict mode never falls back silently)
 bool launch_update_flow_strict(const float* Rstack, const float* Min, float* Mout, float* flow, PairBatch pb,
                                int H, int W, int winsize, hipStream_t st)
 {
     if (pb.npairs <= 0) return true;
     const int m = winsize / 2;
-    const size_t bytes = (5 * (size_t)(W + 2 * (m + 1)) + 5 * (size_t)W) * sizeof(double);
+    const size_t bytes = strict_lds_bytes(W, winsize);
     if (bytes > 160 * 1024) return false;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_update_flow_strict, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    // per launch: the attribute belongs to the device's code object and handles may sit on different devices
+    if (hipFuncSetAttribute((const void*)k_update_flow_strict, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
     const double scale = 1. / ((double)winsize * winsize);
     hipLaunchKernelGGL(k_update_flow_strict, dim3(pb.npairs), dim3(256), bytes, st, Rstack, Min, Mout, flow, pb, H, W, m, scale);
     return true;

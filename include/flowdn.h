@@ -69,6 +69,18 @@ int fdn_synchronize(fdn_handle h);
  * memory minus a reserve).  Sweeps are chunked over target slices to respect it. */
 int fdn_set_workspace_limit(fdn_handle h, size_t bytes);
 
+/* Switches of a live handle (tests and experiments; fdn_create reads the same from the environment:
+ * FDN_STRICT_ORDER, FDN_PATH / FDN_FORCE_STAGED, FDN_FUSED_OCC, FDN_LDS_PAD).  Every path gives the same
+ * bits except strict_order:
+ *   "strict_order" 0/1  OpenCV's serial f64 running sum along x in FarnebackUpdateFlow_Blur instead of the
+ *                       direct window sum (about 20x slower; errors out, never falls back, when a row does
+ *                       not fit the LDS)
+ *   "path"         0 automatic, 1 one kernel per Farneback stage, 2 one kernel per iteration
+ *   "fused_occ"    0 automatic, 3..5 workgroups per CU of the 3-iteration fused kernel
+ *   "lds_pad"      bytes of extra dynamic LDS per workgroup of that kernel (occupancy curves)
+ * No counterpart in the reference (cv2 has no such switches). */
+int fdn_set_option(fdn_handle h, const char* name, long value);
+
 /* ---- device memory helpers (so that a host program needs no other HIP binding) ----- */
 int fdn_malloc(fdn_handle h, size_t bytes, void** dptr);
 int fdn_free(fdn_handle h, void* dptr);

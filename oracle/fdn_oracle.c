@@ -43,18 +43,32 @@
  * two exact zeros and returns coeffs[1:-1]: that is scipy's own kernel,
  * radius r = int(truncate*sigma + 0.5) with truncate = 4,
  * w[j] = exp(-0.5/sigma^2 * j^2) / sum.  Returns K = 2r+1 (or -needed if cap too small). */
+/* numpy's float64 add.reduce (pairwise sum: 8 interleaved accumulators per block of <= 128, halving above) */
+static double np_pairwise_sum_f64(const double* a, size_t n)
+{
+    if (n < 8) { double r = 0; for (size_t i = 0; i < n; i++) r += a[i]; return r; }
+    if (n <= 128) {
+        double r[8];
+        size_t i;
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8) for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    size_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum_f64(a, n2) + np_pairwise_sum_f64(a + n2, n - n2);
+}
+
 FDO_EXPORT int fdo_gaussian_kernel(double sigma, double* out, int cap)
 {
     int r = (int)(4.0 * sigma + 0.5);
     int K = 2 * r + 1;
     if (K > cap) return -K;
     double sigma2 = sigma * sigma;
-    double s = 0.0;
-    for (int j = -r; j <= r; j++) {
-        double v = exp(-0.5 / sigma2 * (double)(j * j));
-        out[j + r] = v;
-        s += v;
-    }
+    for (int j = -r; j <= r; j++) out[j + r] = exp(-0.5 / sigma2 * (double)(j * j));
+    double s = np_pairwise_sum_f64(out, (size_t)K);   /* phi_x.sum(): numpy's pairwise reduction */
     for (int i = 0; i < K; i++) out[i] = out[i] / s;
     return K;
 }

@@ -26,12 +26,15 @@ def test_library_exports_every_declared_symbol(fdn):
     assert sorted(fdn._lib.EXPORTS) == declared            # the ctypes layer binds exactly the header
 
 
+from conftest import assert_kernel as _assert_kernel
+
+
 def test_host_only_entry_points(fdn):
     lib = fdn._lib.load()
     assert b"gfx950" in lib.fdn_version()
     g = np.load(os.path.join(ROOT, "tests", "golden", "ref_kernels.npz"))
     for i, s in enumerate(g["sigmas"]):
-        np.testing.assert_allclose(fdn.get_gaussian_kernel(float(s)), g[f"k{i}"], rtol=0, atol=1e-16)
+        _assert_kernel(fdn.get_gaussian_kernel(float(s)), g[f"k{i}"], float(s))
     with pytest.raises(fdn._lib.FlowdnError):
         fdn.get_gaussian_kernel(-1.0)
     # NULL handle is an error with a message, not a crash

@@ -23,13 +23,16 @@ def _img(rng, H, W, amp=200.0, smooth=2.0):
     return (a / np.abs(a).max() * amp).astype(np.float32)
 
 
+from conftest import assert_kernel as _assert_kernel
+
+
 def test_gaussian_kernel_matches_reference_golden(fdn):
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_kernels.npz"))
     for i, s in enumerate(g["sigmas"]):
         k = fdn.get_gaussian_kernel(float(s))
         assert k.shape == g[f"k{i}"].shape
-        np.testing.assert_allclose(k, g[f"k{i}"], rtol=0, atol=1e-16)
+        _assert_kernel(k, g[f"k{i}"], float(s))
 
 
 def test_warp_bit_exact(fdn, oracle):

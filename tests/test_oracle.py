@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import assert_kernel
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -23,7 +25,7 @@ def test_kernel_matches_reference(oracle):
         k = oracle.get_gaussian_kernel(float(s))
         ref = g[f"k{i}"]
         assert k.shape == ref.shape                      # K = 2*int(4 sigma + .5) + 1
-        np.testing.assert_allclose(k, ref, rtol=0, atol=1e-16)
+        assert_kernel(k, ref, float(s))
         assert abs(k.sum() - 1) < 1e-15
 
 
