@@ -10,13 +10,19 @@ resident in HBM.  PyTorch is used for device memory, the synthetic generator and
 torch.distributed/RCCL; all arithmetic of the step runs in libflowdn.so.
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
-  "roofline":     dominant kernel, algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
+  "roofline":     the dominant kernel against the 8 TB/s HBM peak, priced on the bytes that kernel MUST move
+                  (never a fraction above 1); the SURVEY 8(d) stage-list figure sits beside it under
+                  "unfused_algorithmic"; PMC traffic / limiter only from a committed profile of the same sources
+  "sweep":        the warped-Gaussian sweep as its own kernel (north_star's 50 % target), timed after the run
+  "checked":      the timed output re-derived pass by pass and spot-checked against the oracle (after the timed region)
   "cpu_baseline": the CPU oracle (oracle/, a port of the reference's arithmetic parallelised
                   over target slices like src/flowdenoising.py:181-206) on a bounded sample.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,6 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+KERNEL_SOURCES = ("fdn_fused.hip", "fdn_iter.hip", "fdn_device.h", "fdn_kernels.hip")
 
 
 def parse():
@@ -39,73 +47,171 @@ def parse():
     ap.add_argument("--amplitude", type=float, default=100.0)
     ap.add_argument("--levels", type=int, default=0, help="pyramid levels (-l); configs[4] uses 3")
     ap.add_argument("--winsize", type=int, default=5, help="Farneback window (-w); configs[4] uses 15")
+    ap.add_argument("--path", type=int, default=0, help="fdn_set_option path: 0 auto, 1 staged, 2 per-iteration kernels")
     ap.add_argument("--cpu-targets", type=int, default=0, help="target slices of the CPU sample (0 = four per core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check and the sweep-kernel line")
     ap.add_argument("--no-timers", action="store_true", help="skip per-kernel HIP-event timing")
     return ap.parse_args()
 
 
-def algorithmic_bytes(timers, shape, K, axes, levels=0):
-    """SURVEY.md 8(d) per-unit figures x the units each launch processed.
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for fn in KERNEL_SOURCES:
+        p = os.path.join(ROOT, "flowdenoising_amd", "csrc", fn)
+        if os.path.exists(p):
+            with open(p, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
 
-    staged path : FarnebackUpdateFlow_Blur launch = M read 20 B + flow write 8 B per pixel, plus,
-                  on the first iters-1 launches of a chain step, the matrix refresh 68 B
-                  -> (3*28 + 2*68)/3 = 73.33 B per pixel per launch on average.
-    fused path  : one launch = one whole Farneback pair + warp/accumulate = 288 + 12 B per pixel.
-    Every launch covers all target slices of the pass: Z*Y*X pixels."""
-    nvox = shape[0] * shape[1] * shape[2]
-    per_px = {"update_flow": (3 * 28 + 2 * 68) / 3.0, "fused": 300.0}
+
+# Bytes one launch of each dominant kernel must move per pixel of the batch:
+#   fused (3 iterations + warp in one launch): R0 20 + R1 20 + neighbour image 4 + accumulator 8 = 52, plus flow in 8 /
+#       flow out 8 on the chain steps that have them ((K-3)/(K-1) of the launches each)
+#   iter (one Farneback iteration per launch): R0 20 + R1 20 + flow in 8 + flow out 8 = 56; the last of three also warps: +12
+#   update_flow (staged FarnebackUpdateFlow_Blur): M 20 + flow 8, plus on the refreshing launches R0 20 + R1 20 + flow 8 + M 20
+def compulsory_bytes_per_px(name, K):
+    if name == "fused":
+        return 52.0 + 16.0 * (K - 3) / (K - 1)
+    if name == "iter":
+        return 56.0 + 12.0 / 3 - 8.0 / 3 * 2.0 / (K - 1)     # the first launch of each side's chain has no flow to read
+    return (3 * 28 + 2 * 68) / 3.0
+
+
+def roofline(timers, nvox, K, levels, run_cfg):
+    """The dominant kernel against the HBM peak, priced on the bytes it has to move."""
+    names = {"fused": "k_farneback_fused", "iter": "k_farneback_iter", "update_flow": "k_update_flow_scan"}
     best = None
-    for name in ("fused", "update_flow"):
+    for name in names:
         ms, cnt = timers.get(name, (0.0, 0))
         if cnt > 0 and (best is None or ms > best[1]):
             best = (name, ms, cnt)
     if best is None:
         return None
     name, ms, cnt = best
-    # with a pyramid a chain step is one launch per level; level k has 4^-k of the pixels
-    bytes_per_launch = per_px[name] * nvox * sum(0.25 ** k for k in range(levels + 1)) / (levels + 1)
-    avg_ms = ms / cnt
-    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-    traffic, traffic_note = measured_traffic(name, nvox)
-    extra = {}
-    if traffic:   # what the DRAM counters saw, and what actually limits the kernel (committed PMC pass)
-        extra["hbm_measured"] = {"GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1),
-                                 "frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                v = json.load(f).get("valu")
-            if v:
-                extra["limiter"] = {"unit": "VALU issue", "utilisation": v["valu_issue_utilisation"], "source": v["source"]}
-        except OSError:
-            pass
-    return {**_roofline_core(name, achieved, traffic, traffic_note, bytes_per_launch, avg_ms, cnt), **extra}
+    # with a pyramid a chain step is one launch (three for `iter`) per level; level k has 4^-k of the pixels
+    px_per_launch = nvox * sum(0.25 ** k for k in range(levels + 1)) / (levels + 1)
+    avg_s = ms / cnt * 1e-3
+    bpp = compulsory_bytes_per_px(name, K)
+    achieved = bpp * px_per_launch / avg_s / 1e9
+    unfused = {"fused": 300.0, "iter": 100.0, "update_flow": (3 * 28 + 2 * 68) / 3.0}[name]
+    r = {"bound": "hbm", "kernel": names[name], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4),
+         "bytes_per_px": round(bpp, 2),
+         "bytes_model": "compulsory HBM bytes of one launch (inputs read once, outputs written once; matrices and "
+                        "intermediate flows that stay on chip are not charged)",
+         "px_per_launch": int(px_per_launch), "avg_launch_ms": round(ms / cnt, 4), "launches": cnt,
+         "unfused_algorithmic": {"bytes_per_px": round(unfused, 1), "GBps": round(unfused * px_per_launch / avg_s / 1e9, 1),
+                                 "note": "SURVEY 8(d) stage list with every named intermediate through HBM; exceeds the "
+                                         "peak exactly when fusion removed that traffic -- not an HBM fraction"},
+         "traffic": None}
+    t = committed_profile(names[name], run_cfg)
+    r["traffic_source"] = t["note"]
+    if t.get("bytes_per_px") is not None:
+        traffic = t["bytes_per_px"] * px_per_launch
+        r["traffic"] = round(traffic)
+        r["traffic_frac"] = round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4)
+        r["overfetch"] = round(t["bytes_per_px"] / bpp, 3)
+        if t.get("limiter"):
+            r["limiter"] = t["limiter"]
+    return r
 
 
-def _roofline_core(name, achieved, traffic, traffic_note, bytes_per_launch, avg_ms, cnt):
-    return {"bound": "hbm", "kernel": {"fused": "k_farneback_fused", "update_flow": "k_update_flow_scan"}[name],
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
-            "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(avg_ms, 4),
-            "launches": cnt}
-
-
-def measured_traffic(name, nvox):
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/), scaled to
-    this run's pixels per launch; None when no PMC data exists for the kernel."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if name != "fused" or not os.path.exists(path):
-        return None, "no PMC pass for this kernel"
-    with open(path) as f:
+def committed_profile(kernel, run_cfg):
+    """PMC traffic of the dominant kernel from profiles/ (tools/profile_round.sh).  Used only when it was taken
+    from the same kernel sources and the same workload as this run; otherwise traffic stays null."""
+    if not os.path.exists(TRAFFIC_FILE):
+        return {"note": "no committed PMC pass"}
+    with open(TRAFFIC_FILE) as f:
         t = json.load(f)
-    scale = nvox / t["pixels_per_launch"]
-    return round(t["bytes_per_launch"] * scale), (
-        f"(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, separate rocprofv3 --pmc passes ({os.path.basename(path)}): "
-        f"{t['bytes_per_pixel']:.0f} B per pixel per launch against 300 algorithmic (M and the per-iteration flows never "
-        "leave the chip) and 68 compulsory")
+    if t.get("kernel") != kernel:
+        return {"note": f"committed PMC pass is for {t.get('kernel')}, not {kernel}"}
+    if t.get("kernel_source_sha") != kernel_source_hash():
+        print(f"bench.py: WARNING: {os.path.basename(TRAFFIC_FILE)} was profiled on other kernel sources "
+              f"({t.get('kernel_source_sha')} != {kernel_source_hash()}): roofline.traffic left null; rerun tools/profile_round.sh",
+              file=sys.stderr)
+        return {"note": "committed PMC pass is STALE (kernel sources changed since): not used"}
+    for key in ("shape", "winsize", "levels", "sigma", "axes"):
+        if t.get("workload", {}).get(key) != run_cfg.get(key):
+            return {"note": f"committed PMC pass is for another workload ({key}): not used"}
+    return {"bytes_per_px": t["bytes_per_pixel"], "limiter": t.get("limiter"),
+            "note": f"source: committed profile {os.path.basename(TRAFFIC_FILE)} (commit {t.get('commit')}, `{t.get('command')}`): "
+                    "(2 x FETCH_SIZE + WRITE_SIZE) per launch from separate rocprofv3 --pmc passes, not measured in this run"}
 
 
-def cpu_baseline(vol_t, shape, kernel, mean, n_targets):
+def sweep_line(h, vol, shape, kernel, params, mean):
+    """north_star states its 50 % target on the warped-Gaussian sweep.  In the product that sweep is fused into the
+    Farneback kernel (its 12 B/px are inside `roofline`); as a kernel of its own it exists on the staged path
+    (k_warp_accumulate): time it there, on a Z pass over the first 64 slices."""
+    from flowdenoising_amd import _lib
+    import torch
+    Z, Y, X = shape
+    n = min(64, Z)
+    out = torch.empty((n, Y, X), dtype=torch.float32, device=vol.device)
+    h.set_option("path", 1)
+    try:
+        h.timers(reset=True)
+        h.filter_axis_dev(vol.data_ptr(), out.data_ptr(), (n, Y, X), 0, kernel, mean, params)
+        torch.cuda.synchronize()
+        tm = h.timers(reset=True)
+    finally:
+        h.set_option("path", 0)
+    ms, cnt = tm["warp"]
+    if not cnt:
+        return None
+    px = n * Y * X
+    avg_s = ms / cnt * 1e-3
+    model, real = 12.0, 20.0
+    return {"kernel": "k_warp_accumulate", "bound": "hbm", "bytes_per_px_model": model,
+            "achieved": round(model * px / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(model * px / avg_s / 1e9 / HBM_PEAK_GBS, 4),
+            "moved_GBps": round(real * px / avg_s / 1e9, 1), "moved_frac": round(real * px / avg_s / 1e9 / HBM_PEAK_GBS, 4),
+            "avg_launch_ms": round(ms / cnt, 4), "launches": cnt,
+            "note": "SURVEY 8(d) prices the sweep at flow 8 + neighbour 4 B per pixel and pair; as a separate kernel it "
+                    f"also reads and writes the f32 accumulator per pair (20 B moved); {n} target slices, staged path"}
+
+
+def check_output(h, vol, out, shape, kernels, params, mean):
+    """After the timed region: redo the step pass by pass (so that each pass's input exists), require the same bits
+    as the timed output, and recompute one target slice of every pass with the oracle from that pass's own input."""
+    import torch
+    from oracle import oracle as O
+    O.build()
+    cur = vol
+    worst = 0.0
+    exact = True
+    passes = []
+    for axis in range(3):
+        k = kernels[axis]
+        if k is None:
+            continue
+        nxt = torch.empty_like(vol)
+        h.filter_axis_dev(cur.data_ptr(), nxt.data_ptr(), shape, axis, k, mean, params)
+        torch.cuda.synchronize()
+        n, r = shape[axis], k.size // 2
+        t = n // 2 + 3
+        lo, hi = max(0, t - r), min(n, t + r + 1)
+        idx = [slice(None)] * 3
+        idx[axis] = slice(lo, hi)
+        sub = cur[tuple(idx)].contiguous().cpu().numpy()
+        idx[axis] = t
+        got = nxt[tuple(idx)].contiguous().cpu().numpy()
+        want = np.take(O.filter_axis_range(sub, axis, k, params.levels, params.winsize, mean, t - lo, t - lo + 1, nthreads=1),
+                       t - lo, axis=axis)
+        err = float(np.abs(got.astype(np.float64) - want).max() / max(float(np.abs(want).max()), 1e-30))
+        worst = max(worst, err)
+        exact = exact and bool(np.array_equal(got, want))
+        passes.append(f"{'ZYX'[axis]}[{t}]")
+        if cur is not vol:
+            del cur
+        cur = nxt
+    same = bool(torch.equal(cur, out))
+    return {"timed_output_equals_pass_by_pass_rerun": same, "slices": passes, "max_rel_err": worst, "bit_equal": exact,
+            "tolerance": 1e-4, "ok": bool(same and worst < 1e-4),
+            "how": "one target slice per pass recomputed by the CPU oracle from the GPU's input of that pass"}
+
+
+def cpu_baseline(vol_t, shape, kernel, mean, n_targets, levels, winsize):
     """Time the oracle's Z pass on `n_targets` target slices taken from the middle of the same
     volume, one chunk of slices per core (par:181-206), and scale to the full three-pass job."""
     from oracle import oracle as O
@@ -123,14 +229,16 @@ def cpu_baseline(vol_t, shape, kernel, mean, n_targets):
     slab = vol_t[z0:z1].cpu().numpy()
     s0 = min(r, slab.shape[0] - n_targets)
     t0 = time.perf_counter()
-    O.filter_axis_range(slab, 0, kernel, 0, 5, mean, s0, s0 + n_targets, nthreads=cores)
+    O.filter_axis_range(slab, 0, kernel, levels, winsize, mean, s0, s0 + n_targets, nthreads=cores)
     dt = time.perf_counter() - t0
     vox = n_targets * Y * X
     per_axis = vox / dt / 1e6
     return {"value": round(per_axis / 3.0, 4), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
-            "sample": f"oracle Z pass on {n_targets} target slices ({Y}x{X}, 16 Farneback pairs each) of the same "
+            "sample": f"oracle Z pass on {n_targets} target slices ({Y}x{X}, {kernel.size - 1} Farneback pairs each) of the same "
                       f"volume in {dt:.1f} s with {cores} threads; per-axis rate {per_axis:.3f} Mvox/s divided by 3 "
-                      "for the Z+Y+X job (same pixel-pair count per axis)"}
+                      "for the Z+Y+X job (same pixel-pair count per axis).  A C port: it leaves out what the reference's "
+                      "Python adds per pair (the numpy grid build of seq:53-55, 42 ms per 1024x1024 call), so the "
+                      "reference itself would be slower than this"}
 
 
 def main():
@@ -161,7 +269,10 @@ def main():
 
     h = _lib.Handle(local_rank)
     h.set_stream(torch.cuda.current_stream().cuda_stream)
+    if a.path:
+        h.set_option("path", a.path)
 
+    eng = None
     if world == 1:
         vol = synth.make_volume(shape, seed=1234 + 3, amplitude=a.amplitude, xp=torch, device=dev)
         out = torch.empty_like(vol)
@@ -189,6 +300,8 @@ def main():
     if not a.no_timers:
         h.enable_timers(True)
         h.timers(reset=True)
+        if eng is not None and hasattr(eng, "reset_phase_times"):
+            eng.reset_phase_times()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -206,7 +319,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     timers = h.timers() if not a.no_timers else {}
-    h.enable_timers(False)
+    phases = None
+    if eng is not None and hasattr(eng, "phase_times") and not a.no_timers:
+        mine = eng.phase_times()          # ms per category on this rank, over the timed steps
+        names = sorted(mine)
+        buf = torch.tensor([mine[n] for n in names], dtype=torch.float64, device=dev)
+        allr = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(allr, buf)
+        phases = {n: [round(float(r[i]) / a.steps, 2) for r in allr] for i, n in enumerate(names)}
 
     if rank == 0:
         nvox = Z * Y * X
@@ -219,18 +339,34 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{X}x{Y}x{Z} float32, sigma={a.sigma:g} (K={kernel.size}), levels={a.levels}, winsize={a.winsize}, "
                                    f"OF along {a.axes.upper()}, mean-padded borders (BASELINE.json configs[2])",
-                       "axes": a.axes, "parallelism": parallelism, "amplitude": a.amplitude},
+                       "axes": a.axes, "parallelism": parallelism, "amplitude": a.amplitude,
+                       "amplitude_note": "BASELINE.md's unit-range generator scaled by 100: OpenCV's absolute +1e-3 regulariser zeroes "
+                                         "every flow on unit-range data.  Throughput depends on it a little: larger flows leave the "
+                                         "kernel's LDS window more often"},
         }
-        # whole path against the SURVEY 8(d) algorithmic traffic (4832 B/voxel/axis at sigma=2)
+        # whole path against the SURVEY 8(d) stage list (4832 B/voxel/axis at sigma=2): what an UNFUSED implementation
+        # would have to move; above the HBM peak it measures traffic removed by fusion, not bandwidth
         per_axis_bytes = 24 + (kernel.size - 1) * 300 + 8
-        res["whole_path"] = {"algorithmic_GBps": round(per_axis_bytes * naxes * nvox / (dt / a.steps) / 1e9 / world, 1),
-                             "frac_of_hbm_peak_per_gpu": round(per_axis_bytes * naxes * nvox / (dt / a.steps) / 1e9 / world / HBM_PEAK_GBS, 4)}
+        res["whole_path"] = {"unfused_algorithmic_GBps": round(per_axis_bytes * naxes * nvox / (dt / a.steps) / 1e9 / world, 1),
+                             "ratio_to_hbm_peak_per_gpu": round(per_axis_bytes * naxes * nvox / (dt / a.steps) / 1e9 / world / HBM_PEAK_GBS, 4),
+                             "note": "SURVEY 8(d) bytes of the unfused stage list / wall time; a ratio above 1 = traffic that fusion removed"}
         if timers:
-            res["roofline"] = algorithmic_bytes(timers, shape if world == 1 else (Z // world, Y, X), kernel.size, a.axes, a.levels)
+            run_cfg = {"shape": list(shape), "winsize": a.winsize, "levels": a.levels, "sigma": a.sigma, "axes": a.axes}
+            res["roofline"] = roofline(timers, nvox // world, kernel.size, a.levels, run_cfg)
             res["kernel_ms_per_step"] = {k: round(v[0] / a.steps, 2) for k, v in timers.items() if v[1]}
+        if phases:
+            res["phase_ms_per_step_per_rank"] = phases
+        if world == 1 and not a.no_check:
+            h.enable_timers(False)
+            res["checked"] = check_output(h, vol, out, shape, kernels, params, mean)
+            h.enable_timers(True)
+            if a.levels == 0:
+                res["sweep"] = sweep_line(h, vol, shape, kernel, params, mean)
+        h.enable_timers(False)
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(vol, shape, kernel, mean, a.cpu_targets)
+            res["cpu_baseline"] = cpu_baseline(vol, shape, kernel, mean, a.cpu_targets, a.levels, a.winsize)
         print(json.dumps(res), flush=True)
+    h.enable_timers(False)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,139 @@
+"""BASELINE.json's five configurations at their stated workload (one GPU; configs[3]'s 1024^3 Z pass is in
+test_gpu_full.py::test_wide_kernel_on_a_gib_volume_spot_parity, configs[1] in its roll-equivariance and
+full-size-image tests).  Where the oracle cannot run the whole volume in seconds, the GPU processes the full
+size and the oracle recomputes the sub-volume that feeds chosen target slices -- a target slice depends only
+on its K neighbours along the pass's axis, so that comparison is exact, not sampled.
+
+Tolerance: north_star asks for 1e-4 relative; the kernels follow the oracle operation by operation, so the
+tests assert bit equality where it has always held and TIGHT_TOL = 2e-6 (max |gpu - oracle| / max |oracle|)
+elsewhere."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TIGHT_TOL = 2e-6
+
+
+def _uint16_range(vol):
+    """What a 12-bit detector stack holds: 0..4095, integers (configs[4]: 'uint16 TIFF stack')."""
+    lo, hi = float(vol.min()), float(vol.max())
+    return np.round((vol - lo) / (hi - lo) * 4095).astype(np.float32)
+
+
+# ---- configs[0]: 128 x 128 x 64 float32 MRC, sigma = 2, default Farneback parameters, through the CLI ----------
+def test_config0_full_size_mrc_cli(fdn, oracle, tmp_path):
+    from flowdenoising_amd import io as fio
+    from flowdenoising_amd.synth import make_volume
+    vol = make_volume((64, 128, 128), seed=1234 + 1, amplitude=100.0)
+    fio.write_mrc(str(tmp_path / "volume.mrc"), vol)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "flowdenoising.py"), "-i", str(tmp_path / "volume.mrc"),
+                        "-o", str(tmp_path / "denoised_volume.mrc")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = fio.read_mrc(str(tmp_path / "denoised_volume.mrc"))
+    k = oracle.get_gaussian_kernel(2.0)                      # seq:49: SIGMA = 2 on every axis
+    want = oracle.OF_filter(vol, [k, k, k], 0, 5, nthreads=16)     # seq:44-45: l = 0, w = 5
+    assert got.dtype == np.float32 and got.shape == vol.shape
+    assert np.array_equal(got, want), rel_err(got, want)
+
+
+# ---- configs[2]: 1024 x 1024 x 512 float32, sigma = 2, Z then Y then X: every pass checked at full volume ------
+def test_config2_each_pass_of_the_full_volume(fdn, oracle):
+    """The bench.py workload.  The three passes run on the whole 2 GiB volume in HBM (fdn_filter_axis_dev per
+    pass, so that each intermediate is available); fdn_filter_3d_dev -- what bench.py times -- must give the
+    same bits as the chain of single passes.  Per pass two target slices (one whose window reaches the mean
+    padding, one interior) are recomputed by the oracle from the 17-slice sub-volume of THAT pass's input, i.e.
+    the Y pass is checked on the GPU's Z-pass output and the X pass on the GPU's Z+Y output."""
+    import torch
+    from flowdenoising_amd import _lib, synth
+    shape = (512, 1024, 1024)
+    dev = torch.device("cuda", 0)
+    h = _lib.Handle(0)
+    vols = {}
+    try:
+        h.set_stream(torch.cuda.current_stream().cuda_stream)
+        vol = synth.make_volume(shape, seed=1234 + 3, amplitude=100.0, xp=torch, device=dev)
+        k = _lib.gaussian_kernel(2.0)
+        params = _lib.SweepParams(0, 5, 3, 5, 1.2, _lib.BORDER_MEAN_PAD, 1, 1)
+        mean = h.mean_dev(vol.data_ptr(), vol.numel())
+        cur = vol
+        checks = []
+        for axis in (0, 1, 2):
+            out = torch.empty_like(vol)
+            h.filter_axis_dev(cur.data_ptr(), out.data_ptr(), shape, axis, k, mean, params)
+            torch.cuda.synchronize()
+            n = shape[axis]
+            for t in (3, n // 2 + 5):
+                lo, hi = max(0, t - 8), min(n, t + 9)
+                idx = [slice(None)] * 3
+                idx[axis] = slice(lo, hi)
+                sub = cur[tuple(idx)].contiguous().cpu().numpy()
+                idx[axis] = t
+                checks.append((axis, t, lo, sub, out[tuple(idx)].contiguous().cpu().numpy()))
+            vols[axis] = out
+            cur = out
+        whole = torch.empty_like(vol)
+        h.filter_3d_dev(vol.data_ptr(), whole.data_ptr(), shape, [k, k, k], mean, params)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(whole, vols[2]))
+        del whole
+    finally:
+        h.close()
+        vols.clear()
+        torch.cuda.empty_cache()
+    assert same, "fdn_filter_3d_dev differs from the chain of fdn_filter_axis_dev passes"
+    for axis, t, lo, sub, got in checks:
+        want = oracle.filter_axis_range(sub, axis, k, 0, 5, mean, t - lo, t - lo + 1, nthreads=1)
+        want = np.take(want, t - lo, axis=axis)
+        assert np.array_equal(got, want), (axis, t, rel_err(got, want))
+
+
+# ---- configs[4]: 2048 x 2048 x 512 uint16 stack, sigma = (2, 2, 4), -l 3 -w 15 --------------------------------
+@pytest.mark.parametrize("axis,shape,sigma,targets", [
+    (0, (24, 2048, 2048), 2.0, (3, 12)),       # Z pass: 2048 x 2048 images, K = 17
+    (1, (512, 20, 2048), 2.0, (3, 10)),        # Y pass: (Z, X) = 512 x 2048 images, K = 17
+    (2, (512, 2048, 36), 4.0, (3, 17)),        # X pass: (Z, Y) = 512 x 2048 images, K = 33
+])
+def test_config4_full_size_images_spot_parity(fdn, oracle, axis, shape, sigma, targets):
+    """Every pass of configs[4] on its full-size images (3 pyramid levels, 15 x 15 window, data in the uint16
+    range), thin along the pass's axis; two targets per pass against the oracle on the sub-volume feeding them."""
+    from flowdenoising_amd.synth import make_volume
+    vol = _uint16_range(make_volume(shape, seed=1234 + 5, amplitude=100.0))
+    k = fdn.get_gaussian_kernel(sigma)
+    r = k.size // 2
+    mean = vol.mean()
+    fn = [fdn.OF_filter_along_Z, fdn.OF_filter_along_Y, fdn.OF_filter_along_X][axis]
+    got = fn(vol, k, 3, 15, mean)
+    n = shape[axis]
+    for t in targets:
+        lo, hi = max(0, t - r), min(n, t + r + 1)
+        sub = np.take(vol, range(lo, hi), axis=axis)
+        want = oracle.filter_axis_range(sub, axis, k, 3, 15, mean, t - lo, t - lo + 1, nthreads=1)
+        assert rel_err(np.take(got, [t], axis=axis), np.take(want, [t - lo], axis=axis)) < TIGHT_TOL, (axis, t)
+
+
+def test_config4_uint16_tiff_cli_end_to_end(fdn, oracle, tmp_path):
+    """uint16 multi-page TIFF -> flowdenoising.py -s 2 2 4 -l 3 -w 15 -> TIFF, 2048 x 2048 pages, thin in Z:
+    float32 conversion on input (seq:517), uint8/uint16 down-cast on output (seq:566-571: astype truncates)."""
+    from flowdenoising_amd import io as fio
+    from flowdenoising_amd.synth import make_volume
+    vol16 = _uint16_range(make_volume((10, 2048, 2048), seed=1234 + 5, amplitude=100.0)).astype(np.uint16)
+    fio.write_tiff(str(tmp_path / "stack.tif"), vol16)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "flowdenoising.py"), "-i", str(tmp_path / "stack.tif"),
+                        "-o", str(tmp_path / "denoised.tif"), "-s", "2", "2", "4", "-l", "3", "-w", "15"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = fio.read_tiff(str(tmp_path / "denoised.tif"))
+    ks = [oracle.get_gaussian_kernel(s) for s in (2.0, 2.0, 4.0)]
+    want = oracle.OF_filter(vol16.astype(np.float32), ks, 3, 15, nthreads=16)
+    assert want.max() >= 256 and got.dtype == np.uint16 and got.shape == vol16.shape
+    want16 = want.astype(np.uint16)
+    # a float32 difference below TIGHT_TOL may still cross an integer boundary under truncation
+    diff = np.abs(got.astype(np.int32) - want16.astype(np.int32))
+    assert diff.max() <= 1 and np.count_nonzero(diff) <= 1e-6 * diff.size, (int(diff.max()), int(np.count_nonzero(diff)))

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Dump real-cv2 fixtures into tests/golden/ (run on any box where `import cv2` works; none in this
+pipeline so far -- see DESIGN.md 5).  cv2 is called directly by this harness (tests/test_cv2_pin.py's
+helpers); the reference's files are not involved.  Outputs are data only: seeded inputs + cv2's results.
+
+  cv2_pair_<H>x<W>_l<l>_w<w>.npz   target, reference, init flow, cv2 flow, cv2-warped reference
+  cv2_config0.npz                  128x128x64 volume (BASELINE configs[0]), sigma 2, l 0, w 5 -> seq-shaped result
+
+After committing them, change DESIGN.md 5 to say "pinned by cv2 fixtures" (tests/test_cv2_pin.py checks it)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import cv2
+    import test_cv2_pin as T
+    from flowdenoising_amd.synth import make_volume
+    print("cv2", cv2.__version__)
+    for shape in T.PAIR_SHAPES[:2]:
+        for l, w in T.PAIR_PARAMS:
+            a, b, f0 = T.make_pair(shape, 100 + shape[0])
+            flow = T.cv2_flow(cv2, a, b, l, w, f0)
+            np.savez_compressed(os.path.join(T.GOLD, f"cv2_pair_{shape[0]}x{shape[1]}_l{l}_w{w}.npz"), target=a, reference=b,
+                                init=f0, flow=flow, warped=T.cv2_warp(cv2, b, flow), l=l, w=w, cv2_version=cv2.__version__)
+    vol = make_volume((64, 128, 128), seed=1234 + 1, amplitude=100.0)
+    from oracle import oracle as O
+    k = O.get_gaussian_kernel(2.0)
+    out = T.cv2_of_filter(cv2, vol, [k, k, k], 0, 5)
+    np.savez_compressed(os.path.join(T.GOLD, "cv2_config0.npz"), vol=vol, out=out, sigma=2.0, l=0, w=5, cv2_version=cv2.__version__)
+    print("written to", T.GOLD)
+
+
+if __name__ == "__main__":
+    main()

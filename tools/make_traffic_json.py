@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 --pmc passes of tools/profile_round.sh into profiles/<round>_traffic.json, the file bench.py
+reads for roofline.traffic / roofline.limiter.  It is stamped with the hash of the kernel sources, the commit and
+the workload it was taken on; bench.py ignores it (traffic = null, loud warning) when any of them differs.
+
+usage: make_traffic_json.py <kernel substring> <out.json> <commit> [pmc glob]"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (kernel_source_hash, the one definition)
+
+kern, out, commit = sys.argv[1], sys.argv[2], sys.argv[3]
+pat = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "gpurun_out/pmc*/**/*_counter_collection.csv")
+acc = collections.defaultdict(list)
+for f in sorted(glob.glob(pat, recursive=True)):
+    for r in csv.DictReader(open(f)):
+        if kern in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+mean = {k: sum(v) / len(v) for k, v in acc.items()}
+if "FETCH_SIZE" not in mean or "WRITE_SIZE" not in mean:
+    sys.exit(f"no FETCH_SIZE/WRITE_SIZE rows for {kern} under {pat}")
+shape = [512, 1024, 1024]
+px = shape[0] * shape[1] * shape[2]
+# FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE x 2 is the guide's gfx950 correction (128-B fabric reads tallied at 64 B)
+nbytes = (2 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024
+res = {
+    "kernel": kern,
+    "kernel_source_sha": bench.kernel_source_hash(),
+    "commit": commit,
+    "command": "rocprofv3 --pmc <set> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-timers --no-check "
+               "(separate passes per counter set, tools/profile_round.sh)",
+    "workload": {"shape": shape, "winsize": 5, "levels": 0, "sigma": 2.0, "axes": "zyx"},
+    "launches_averaged": len(acc["FETCH_SIZE"]),
+    "fetch_size_kib_per_launch": mean["FETCH_SIZE"], "write_size_kib_per_launch": mean["WRITE_SIZE"],
+    "correction": "FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM section; re-checked on known byte counts by "
+                  "tools/ubench/fetch_calib.hip); WRITE_SIZE as is",
+    "bytes_per_launch": nbytes, "pixels_per_launch": px, "bytes_per_pixel": nbytes / px,
+}
+if "SQ_INSTS_VALU" in mean and "GRBM_GUI_ACTIVE" in mean:
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; a wave64 VALU instruction holds its SIMD's issue for 4 cycles
+    cycles = mean["GRBM_GUI_ACTIVE"] / 8
+    util = mean["SQ_INSTS_VALU"] * 4 / (1024 * cycles)
+    res["limiter"] = {"unit": "VALU issue", "utilisation": round(util, 3),
+                      "sq_insts_valu_per_launch": mean["SQ_INSTS_VALU"], "gpu_cycles_per_launch": cycles,
+                      "lds_bank_conflict_share": round(mean.get("SQ_LDS_BANK_CONFLICT", 0) / max(mean.get("SQ_LDS_IDX_ACTIVE", 1), 1), 3),
+                      "source": "same --pmc passes (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))"}
+res["all_counters_mean_per_launch"] = mean
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps({k: res[k] for k in ("kernel", "bytes_per_pixel", "kernel_source_sha")}), res.get("limiter"))
