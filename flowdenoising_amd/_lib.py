@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libflowdn.so")
 USE_INITIAL_FLOW = 4
 BORDER_MEAN_PAD = 0
 BORDER_WRAP = 1
-TIMER_NAMES = ("polyexp", "update_matrices", "update_flow", "warp", "permute", "transfer", "fused")
+TIMER_NAMES = ("polyexp", "update_matrices", "update_flow", "warp", "permute", "transfer", "fused", "iter")
 
 
 class FlowdnError(RuntimeError):

@@ -437,6 +437,43 @@ static int pyramid_step_fused(fdn_ctx* h, const std::vector<PyrLevel>& lv, const
     return 0;
 }
 
+// One chain step on the one-iteration kernels (fdn_iter.hip): calc()'s levels, coarsest first, `iters` launches each;
+// the last launch of level 0 also warps the neighbour and accumulates.  bufs: two full-resolution flow buffers; `prev`
+// (one of them, or nullptr) holds the previous step's flow.  *result = where this step's flow is (when keep).
+static int chain_step_iter(fdn_ctx* h, const std::vector<PyrLevel>& lv, const float* R0, const float* stack, const float* prev,
+                           float* const bufs[2], float* acc, PairBatch pb, int H, int W, int winsize, int iters, double weight,
+                           bool keep, float** result)
+{
+    const int L = (int)lv.size() - 1;
+    float* fp = (float*)h->flow_pyr.p;
+    const int n = pb.npairs;
+    const float* fin = prev;         // flow handed to the next launch
+    int ch = 0, cw = 0;              // its size when it is a coarser level's
+    if (L > 0 && prev) {             // coarsest level starts from the INTER_AREA shrink of the previous flow, times its scale
+        float* a = fp + lv[L].f_off;
+        ScopedTimer t(h, FDN_TIMER_PERMUTE);
+        if (resize_dev(h, prev, H, W, a, lv[L].h, lv[L].w, 2, n, 3, true, lv[L].scale)) return -1;
+        fin = a;
+    }
+    for (int k = L; k >= 0; k--) {
+        float* A = k ? fp + lv[k].f_off : bufs[0];
+        float* B = k ? A + (size_t)n * lv[k].h * lv[k].w * 2 : bufs[1];
+        const float* Rk = k ? (const float*)h->Rpyr.p + lv[k].r_off : R0;
+        for (int it = 0; it < iters; it++) {
+            const bool last = k == 0 && it == iters - 1;
+            float* fout = fin == A ? B : A;
+            ScopedTimer t(h, FDN_TIMER_ITER);
+            if (launch_farneback_iter(Rk, stack, fin, last && !keep ? nullptr : fout, last ? acc : nullptr, pb, lv[k].h, lv[k].w,
+                                      winsize, weight, h->stream, ch, cw))
+                return fail("k_farneback_iter could not be launched (winsize %d needs %zu bytes of LDS)", winsize, iter_lds_bytes(winsize / 2));
+            fin = fout; ch = cw = 0;
+        }
+        ch = lv[k].h; cw = lv[k].w;   // the next (finer) level upsamples this one's result
+    }
+    *result = const_cast<float*>(fin);
+    return 0;
+}
+
 static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H, int W, const double* kernel, int K,
                        const fdn_sweep_params* p)
 {
@@ -471,10 +508,14 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
     if (pyramid && build_R_pyramid(h, stack, nstack, H, W, lv, pc)) return -1;
     bool fused = fused_supported(p->winsize, p->iters, H, W) && h->tn.path == 0 && !h->tn.strict_order;
     for (size_t k = 1; k < lv.size(); k++) fused = fused && fused_supported(p->winsize, p->iters, lv[k].h, lv[k].w);
+    // windows the 3-iteration kernel does not cover (winsize >= 10): one launch per iteration, matrices in LDS
+    bool iter = !fused && p->iters >= 1 && h->tn.path != 1 && !h->tn.strict_order && iter_supported(p->winsize, H, W);
+    for (size_t k = 1; k < lv.size(); k++) iter = iter && iter_supported(p->winsize, lv[k].h, lv[k].w);
+    if (h->tn.path == 2 && !iter) return fail("path 2 (one-iteration kernels) cannot run winsize %d, iters %d here", p->winsize, p->iters);
     // targets per batch, bounded by the workspace limit.  fused: two flow buffers (16 B/px), with a
     // pyramid two more per coarser level;
     // staged: flow 8 B + two M sets 40 B per pixel
-    size_t per_target = HW * (fused ? (pyramid ? 22 : 16) : pyramid ? 52 : 48);
+    size_t per_target = HW * (fused || iter ? (pyramid ? 22 : 16) : pyramid ? 52 : 48);
     size_t budget = h->ws_limit;
     if (!budget) {
         size_t fre = 0, tot = 0;
@@ -484,7 +525,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
     }
     int C = (int)std::min<size_t>((size_t)S, std::max<size_t>(1, budget / per_target));
     float* R = (float*)h->R.p;
-    if (fused) {
+    if (fused || iter) {
         if (ensure(h, h->flow, (size_t)C * HW * 16)) return -1;
         if (pyramid && ensure_flow_pyramid(h, lv, C, 2)) return -1;
     } else {
@@ -519,6 +560,19 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
                     launch_farneback_fused(R, stack, fin, keep ? fout : nullptr, acc, PairBatch{n, r + c0, d}, H, W,
                                            p->winsize, p->iters, kernel[r + d], st, h->tn);
                     if (keep) { fin = fout; fout = fout == flow ? flowB : flow; }
+                }
+                continue;
+            }
+            if (iter) {
+                float* const bufs[2] = {flow, flowB};
+                const float* prev = nullptr;         // seq:94,109: the chain restarts from zero flow
+                for (int step = 0; step < r; step++) {
+                    int d = side == 0 ? -(step + 1) : (step + 1);
+                    bool keep = p->chained && step + 1 < r;
+                    float* res = nullptr;
+                    if (chain_step_iter(h, lv, R, stack, prev, bufs, acc, PairBatch{n, r + c0, d}, H, W, p->winsize, p->iters,
+                                        kernel[r + d], keep, &res)) return -1;
+                    prev = keep ? res : nullptr;
                 }
                 continue;
             }

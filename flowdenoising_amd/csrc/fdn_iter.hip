@@ -1,0 +1,240 @@
+// fdn_iter.hip -- one Farneback ITERATION per launch, for any window size: the wide-window path
+// (winsize >= 10; BASELINE configs[4] runs -l 3 -w 15, src/flowdenoising.py:48 defaults to 3 levels).
+//
+// cv2.calcOpticalFlowFarneback (src/flowdenoising_sequential.py:62) per level: M = UpdateMatrices(flow);
+// 3 x { flow = solve(box_w(M)); M = UpdateMatrices(flow) }.  The 3-iteration kernel of fdn_fused.hip keeps all
+// of that on chip, but every fused iteration costs w/2 columns of validity either side of a 64-column band
+// (22 of 64 lanes left at winsize 15) and 2 (w/2) + 2 rows of matrices per stage.  Here ONE launch is
+//     M = UpdateMatrices(R0, R1, flow_in)   ->   flow_out = solve(box_w(M))   [last iteration: + warp, accumulate]
+// so a band loses w/2 columns per side once (50 of 64 lanes at winsize 15), the matrices still never reach
+// HBM, and what an iteration costs in HBM is its operands: R0 20 + R1 20 + flow in 8 + flow out 8 bytes per
+// pixel (the staged kernels move 308 per chain step, three of these launches 180).
+//
+// Workgroup = 128 threads = one 64-column band of one (target, neighbour) pair, marching down the rows:
+//   wave 0 (producer)  row t         : M row from flow_in, R0 and the bilinear gather of R1 -> LDS ring slot t % RS
+//   wave 1 (consumer)  row t - MH - 1: OpenCV's vertical running sum vsum += f32(M[y+MH] - M[y-MH-1]) (carried in
+//                                      registers from row 0: the f32-fed recurrence is what makes results bit-faithful,
+//                                      DESIGN.md 3.2), horizontal window across lanes through a per-wave LDS row,
+//                                      2 x 2 solve, store; on the last iteration of level 0 the 1/32-px remap of the
+//                                      neighbour and acc = f32(f64(acc) + f64(v) w) (seq:106-107)
+//   one s_barrier per row step; the ring holds rows t - 2 MH - 2 .. t (RS = 2 MH + 3 rows x 1280 B): what the
+//   producer writes in step t nobody reads in step t.
+// LDS per workgroup at winsize 15: 21.8 KB ring + 3.1 KB window row = 24.9 KB -> 6 workgroups = 12 waves per CU.
+#include "fdn_internal.h"
+#include "fdn_device.h"
+
+namespace fdn {
+
+static __device__ __forceinline__ void lds_barrier_iter()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// MHT: window half-width when known at compile time (0: runtime mh).  FIN 0: zero initial flow, 1: flow_in has the
+// image's size, 2: flow_in is the next coarser level's (fs.h x fs.w) result, resized INTER_LINEAR and doubled on the fly
+// (calc()'s upsampling).  ACC: also warp the neighbour with the new flow and accumulate.
+template <int MHT, int FIN, bool ACC>
+__global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict__ Rstack, const float* __restrict__ stack,
+                                                        const float* __restrict__ flow_in_base, float* __restrict__ flow_out_base,
+                                                        float* __restrict__ acc_base, PairBatch pb, int H, int W, int mh_rt,
+                                                        double scale, double weight, int nbands, FlowSource fs)
+{
+    const int MH = MHT ? MHT : mh_rt;
+    const int RS = 2 * MH + 3;
+    const int BW = 64 - 2 * MH;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // ring row: [ (m0, m2) x 64 ][ (m3, m4) x 64 ][ m1 x 64 ] floats; then the consumer's window row: 5 x (64 + 2 MH) doubles
+    float* ring = lds;
+    double* xch = (double*)(lds + (size_t)RS * 320);
+    const int XP = 64 + 2 * MH;
+
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // XCD-aware order as in k_farneback_fused: XCD j gets the j-th contiguous eighth of the (pair, band) list
+    const long nwg = gridDim.x, q8 = nwg >> 3, rem8 = nwg & 7;
+    const long xcd = blockIdx.x & 7;
+    const long gw = xcd * q8 + (xcd < rem8 ? xcd : rem8) + (blockIdx.x >> 3);
+    const int b = (int)(gw / nbands);
+    const int band = (int)(gw - (long)b * nbands);
+    const int xb = band * BW - MH;
+    const int x = xb + lane;
+    const int xc = clampi(x, 0, W - 1);       // lanes outside the image replicate the border column (BORDER_REPLICATE of vsum)
+    const size_t HW = (size_t)H * W;
+    const int T = H + MH + 1;                 // row steps = barriers both waves execute
+
+    if (role == 0) {
+        // ===== producer ==================================================================================
+        const float* R0 = Rstack + (size_t)(pb.t0 + b) * 5 * HW;
+        const float* R1 = Rstack + (size_t)(pb.t0 + b + pb.d) * 5 * HW;
+        const RImage R0i = {uniform_ptr(R0), uniform_ptr(R0 + 2 * HW), uniform_ptr(R0 + 4 * HW)};
+        const RImage R1i = {uniform_ptr(R1), uniform_ptr(R1 + 2 * HW), uniform_ptr(R1 + 4 * HW)};
+        const float* flow_in = FIN == 1 ? uniform_ptr(flow_in_base + (size_t)b * HW * 2)
+                             : FIN == 2 ? uniform_ptr(flow_in_base + (size_t)b * fs.h * fs.w * 2) : nullptr;
+        const LinearTap ftx = FIN == 2 ? linear_tap(xc, fs.sx, fs.w) : LinearTap{};
+        auto load_flow = [&](int row) __attribute__((always_inline)) -> float2 {
+            if (FIN == 1) return ld_off<float2>(flow_in, ((unsigned)row * (unsigned)W + (unsigned)xc) * 8u);
+            if (FIN == 2) return resize_linear_flow(flow_in, fs.w, ftx, linear_tap(row, fs.sy, fs.h), 2.0);
+            return make_float2(0.f, 0.f);
+        };
+        const float bxx = border_factor(xc, W);
+        const bool xdamp = border_test(xc, W);
+        const float xf = (float)xc;
+        // operands of row 0; inside the loop always one row ahead, the gather of row t + 1 issued before row t is finished
+        float2 fA = load_flow(0);
+        fdn_v2f a01, a23; float a4;
+        load_R(R0i, (unsigned)xc, a01, a23, a4);
+        int x1A, y1A; float fxA, fyA;
+        flow_target(xf, 0.f, fA.x, fA.y, x1A, y1A, fxA, fyA);
+        GatherTapsP gA;
+        gather_R1_p(R1i, H, W, x1A, y1A, gA);
+        int slot = 0;
+        for (int t = 0; t < T; t++) {
+            if (t < H) {
+                // row t + 1: operands and gather in flight while row t is turned into M
+                const int tn = t + 1 < H ? t + 1 : H - 1;
+                const float2 fB = load_flow(tn);
+                fdn_v2f b01, b23; float b4;
+                load_R(R0i, (unsigned)tn * (unsigned)W + (unsigned)xc, b01, b23, b4);
+                int x1B, y1B; float fxB, fyB;
+                flow_target(xf, (float)tn, fB.x, fB.y, x1B, y1B, fxB, fyB);
+                GatherTapsP gB;
+                gather_R1_p(R1i, H, W, x1B, y1B, gB);
+
+                const float by0 = t < 5 ? (t < 2 ? 0.14f : 0.4472f) : 1.f;
+                const float by1 = t >= H - 5 ? (H - t - 1 < 2 ? 0.14f : 0.4472f) : 1.f;
+                fdn_v2f m02, m34; float m1;
+                finish_M_p(a01, a23, a4, gA, H, W, x1A, y1A, fxA, fyA, fA.x, fA.y, bxx, by0, by1, xdamp || border_test(t, H), m02, m1, m34);
+                float* row = ring + (size_t)slot * 320;
+                *(fdn_v2f*)(row + 2 * lane) = m02;
+                *(fdn_v2f*)(row + 128 + 2 * lane) = m34;
+                row[256 + lane] = m1;
+                slot = slot + 1 == RS ? 0 : slot + 1;
+                fA = fB; a01 = b01; a23 = b23; a4 = b4; x1A = x1B; y1A = y1B; fxA = fxB; fyA = fyB; gA = gB;
+            }
+            lds_barrier_iter();
+        }
+        return;
+    }
+
+    // ===== consumer ======================================================================================
+    const bool owner = lane >= MH && lane < 64 - MH && x < W;
+    const float* img1 = ACC ? uniform_ptr(stack + (size_t)(pb.t0 + b + pb.d) * HW) : nullptr;
+    float2* flow_out = flow_out_base ? uniform_ptr((float2*)flow_out_base + (size_t)b * HW) : nullptr;
+    float* acc = ACC ? uniform_ptr(acc_base + (size_t)b * HW) : nullptr;
+    auto ring_row = [&](int r, float m[5]) __attribute__((always_inline)) {       // channels in OpenCV's order m0..m4
+        const float* row = ring + (size_t)(r % RS) * 320;
+        const fdn_v2f p = *(const fdn_v2f*)(row + 2 * lane), q = *(const fdn_v2f*)(row + 128 + 2 * lane);
+        m[0] = p.x; m[2] = p.y; m[3] = q.x; m[4] = q.y; m[1] = row[256 + lane];
+    };
+    double vs[5] = {0., 0., 0., 0., 0.};
+    for (int t = 0; t < T; t++) {
+        if (t == MH) {   // rows 0 .. MH-1 are in the ring: vsum before row 0 = f32(M[0] (MH + 2)) + rows 1 .. MH-1 (clamped)
+            float m[5];
+            ring_row(0, m);
+#pragma unroll
+            for (int c = 0; c < 5; c++) vs[c] = (double)(m[c] * (float)(MH + 2));
+            for (int yy = 1; yy < MH; yy++) {
+                ring_row(yy < H - 1 ? yy : H - 1, m);
+#pragma unroll
+                for (int c = 0; c < 5; c++) vs[c] += (double)m[c];
+            }
+        } else if (t > MH) {
+            const int y = t - MH - 1;
+            const unsigned o = (unsigned)y * (unsigned)W + (unsigned)xc;
+            float acc_old = 0.f;
+            if (ACC) acc_old = ld_off<float>(acc, o * 4u);      // does not depend on this step's flow: load it first
+            float lead[5], trail[5];
+            ring_row(y + MH < H - 1 ? y + MH : H - 1, lead);
+            ring_row(y - MH - 1 > 0 ? y - MH - 1 : 0, trail);
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                vs[c] += (double)(lead[c] - trail[c]);
+                xch[c * XP + lane + MH] = vs[c];
+            }
+            // only this wave reads what it wrote and a wave's LDS operations execute in order; the fences keep the
+            // compiler from moving the reads across the writes (other lanes' addresses)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            double a[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const double* w = xch + c * XP + lane;
+                double s = w[0];                  // the 2 MH + 1 terms left to right, starting from the first
+                if (MHT) {
+#pragma unroll
+                    for (int k = 1; k <= 2 * MHT; k++) s += w[k];
+                } else {
+                    for (int k = 1; k <= 2 * MH; k++) s += w[k];
+                }
+                a[c] = s;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float2 f = solve_flow(a, scale);
+            if (ACC) {
+                const float warped = remap_sample(img1, H, W, xc, y, f);
+                const float acc_new = (float)((double)acc_old + (double)warped * weight);
+                if (owner) {
+                    if (flow_out) st_off(flow_out, o * 8u, f);
+                    st_off(acc, o * 4u, acc_new);
+                }
+            } else if (owner) {
+                st_off(flow_out, o * 8u, f);
+            }
+        }
+        lds_barrier_iter();
+    }
+}
+
+bool iter_supported(int winsize, int H, int W)
+{
+    const int mh = winsize / 2;
+    // the window row needs 2 mh < 64 columns left for outputs; pixels are addressed by 32-bit byte offsets
+    return mh >= 1 && mh <= 24 && H >= 2 && W >= 2 && H < (1 << 24) && W < (1 << 24) && (size_t)H * W < ((size_t)1 << 29);
+}
+
+size_t iter_lds_bytes(int mh) { return (size_t)(2 * mh + 3) * 320 * sizeof(float) + (size_t)5 * (64 + 2 * mh) * sizeof(double); }
+
+template <int MHT>
+static int launch_iter_t(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc, PairBatch pb,
+                         int H, int W, int mh, double scale, double weight, FlowSource fs, hipStream_t st)
+{
+    const int BW = 64 - 2 * mh;
+    const int nbands = (W + BW - 1) / BW;
+    dim3 grid((unsigned)((long)nbands * pb.npairs));
+    const size_t lds = iter_lds_bytes(mh);
+    const int fin = !flow_in ? 0 : fs.h > 0 ? 2 : 1;
+    auto launch = [&](auto kern) -> int {
+        if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        hipLaunchKernelGGL(kern, grid, dim3(128), lds, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, nbands, fs);
+        return 0;
+    };
+    if (acc) {
+        if (fin == 2) return launch(k_farneback_iter<MHT, 2, true>);
+        if (fin == 1) return launch(k_farneback_iter<MHT, 1, true>);
+        return launch(k_farneback_iter<MHT, 0, true>);
+    }
+    if (fin == 2) return launch(k_farneback_iter<MHT, 2, false>);
+    if (fin == 1) return launch(k_farneback_iter<MHT, 1, false>);
+    return launch(k_farneback_iter<MHT, 0, false>);
+}
+
+// One iteration for every pair of the batch.  flow_in: nullptr = zero flow; coarse_h, coarse_w > 0: flow_in is the next
+// coarser level's flow of that size.  acc != nullptr: this is the last iteration of the finest level: warp + accumulate
+// (flow_out may then be nullptr when nobody needs the flow).  flow_in and flow_out must be different buffers.
+int launch_farneback_iter(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
+                          PairBatch pb, int H, int W, int winsize, double weight, hipStream_t st, int coarse_h, int coarse_w)
+{
+    if (pb.npairs <= 0) return 0;
+    FlowSource fs{coarse_h, coarse_w, coarse_h > 0 ? (double)coarse_w / W : 1.0, coarse_h > 0 ? (double)coarse_h / H : 1.0};
+    const double scale = 1. / ((double)winsize * winsize);
+    const int mh = winsize / 2;
+    switch (mh) {   // compile-time windows for the usual sizes; anything else takes the runtime-width build
+    case 2: return launch_iter_t<2>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st);
+    case 5: return launch_iter_t<5>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st);
+    case 7: return launch_iter_t<7>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st);
+    default: return launch_iter_t<0>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st);
+    }
+}
+
+} // namespace fdn

@@ -167,7 +167,8 @@ int fdn_permute_dev(fdn_handle h, const float* d_in, float* d_out, int A, int B,
 #define FDN_TIMER_PERMUTE 4          /* slab re-orientation / halo fill                         */
 #define FDN_TIMER_TRANSFER 5         /* H2D / D2H                                               */
 #define FDN_TIMER_FUSED 6            /* fused Farneback chain-step kernel (fast path)           */
-#define FDN_TIMER_COUNT 7
+#define FDN_TIMER_ITER 7             /* one-iteration Farneback kernel (wide windows)            */
+#define FDN_TIMER_COUNT 8
 /* HIP-event timing of the phases above on the handle's stream.  Event pairs are recorded
  * asynchronously (no host sync inside the timed work) and resolved by fdn_get_timers, which
  * returns accumulated milliseconds and the number of timed launches per category. */

@@ -97,19 +97,68 @@ def test_small_workspace_chunks_targets(fdn, oracle):
     assert rel_err(got, oracle.filter_along_axis(vol, 0, k, 0, 5, vol.mean())) < TIGHT_TOL
 
 
-def test_wide_window_uses_the_staged_path(fdn, oracle):
-    """winsize 15 (BASELINE configs[4]) goes through the general per-stage kernels."""
+def test_wide_window_small_image(fdn, oracle):
+    """winsize 15 (BASELINE configs[4]) on an image narrower than one band of the one-iteration kernel."""
     vol = _vol((6, 48, 52), seed=10)
     k = fdn.get_gaussian_kernel(0.5)
     got = fdn.OF_filter_along_Z(vol, k, 0, 15, vol.mean())
     assert rel_err(got, oracle.filter_along_axis(vol, 0, k, 0, 15, vol.mean())) < TIGHT_TOL
 
 
-@pytest.mark.parametrize("env", [{}, {"FDN_FUSED_OCC": "3"}, {"FDN_FUSED_OCC": "5"}, {"FDN_FORCE_STAGED": "1"}])
+@pytest.mark.parametrize("w", [10, 11, 13, 15, 17, 21, 31])
+@pytest.mark.parametrize("l", [0, 2])
+def test_iter_kernel_window_sizes(fdn, oracle, w, l):
+    """winsize >= 10 runs on k_farneback_iter (one Farneback iteration per launch, matrices in an LDS ring):
+    compile-time windows (11, 15) and the runtime-width build, multi-band images with interior and edge
+    bands, chains of four steps, with and without pyramid; bit-equal to the oracle."""
+    vol = _vol((7, 130, 300), seed=61 + w)
+    k = fdn.get_gaussian_kernel(1.0)
+    got = fdn.OF_filter(vol, [k, None, k], l, w)
+    want = oracle.OF_filter(vol, [k, None, k], l, w, nthreads=8)
+    assert np.array_equal(got, want), (w, l, rel_err(got, want))
+
+
+def test_paths_can_be_switched_on_a_live_handle(fdn, oracle):
+    """fdn_set_option("path"): the same sweep on the 3-iteration fused kernel, the staged kernels and the
+    one-iteration kernels of one handle gives the same bits; unknown options are errors."""
+    from flowdenoising_amd._lib import FlowdnError
+    from flowdenoising_amd.operators import handle
+    vol = _vol((8, 70, 200), seed=14)
+    k = fdn.get_gaussian_kernel(1.0)
+    h = handle()
+    outs = []
+    try:
+        for path in (0, 1, 2):
+            h.set_option("path", path)
+            outs.append(fdn.OF_filter_along_Z(vol, k, 1, 5, vol.mean()))
+        with pytest.raises(FlowdnError):
+            h.set_option("no_such_option", 1)
+    finally:
+        h.set_option("path", 0)
+    want = oracle.filter_along_axis(vol, 0, k, 1, 5, vol.mean(), nthreads=8)
+    for o in outs:
+        assert np.array_equal(o, want)
+
+
+def test_strict_order_refuses_rows_it_cannot_hold(fdn):
+    """Strict mode never falls back silently: a row too wide for the LDS of its serial kernel is an error."""
+    from flowdenoising_amd._lib import FlowdnError
+    from flowdenoising_amd.operators import handle
+    vol = np.zeros((3, 4, 2300), np.float32)
+    h = handle()
+    h.set_option("strict_order", 1)
+    try:
+        with pytest.raises(FlowdnError, match="strict"):
+            fdn.OF_filter_along_Z(vol, fdn.get_gaussian_kernel(0.5), 0, 5, 0.0)
+    finally:
+        h.set_option("strict_order", 0)
+
+
+@pytest.mark.parametrize("env", [{}, {"FDN_FUSED_OCC": "3"}, {"FDN_FUSED_OCC": "5"}, {"FDN_FORCE_STAGED": "1"}, {"FDN_PATH": "2"}])
 def test_kernel_variants_agree_bit_for_bit(fdn, oracle, tmp_path, env):
     """Every implementation of the chain step (the fused stage-pipelined kernel in its builds for 3, 4
-    and 5 workgroups per CU -- different LDS windows and unrolls -- and the staged per-iteration
-    kernels) must give the oracle's bits on a multi-band image with interior and edge bands."""
+    and 5 workgroups per CU -- different LDS windows and unrolls -- the staged per-stage
+    kernels and the one-iteration kernels) must give the oracle's bits on a multi-band image with interior and edge bands."""
     vol = _vol((10, 70, 300), seed=12)
     np.save(tmp_path / "v.npy", vol)
     code = ("import sys, numpy as np; sys.path.insert(0, %r); import flowdenoising_amd as fd; v = np.load(%r); "
