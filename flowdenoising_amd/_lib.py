@@ -31,7 +31,8 @@ class SweepParams(ctypes.Structure):
 EXPORTS = [
     "fdn_create", "fdn_destroy", "fdn_last_error", "fdn_set_stream", "fdn_reset_stream", "fdn_synchronize",
     "fdn_set_workspace_limit", "fdn_set_option", "fdn_malloc", "fdn_free", "fdn_memcpy_h2d", "fdn_memcpy_d2h",
-    "fdn_memset_f32", "fdn_gaussian_kernel", "fdn_farneback", "fdn_warp",
+    "fdn_memset_f32", "fdn_gaussian_kernel", "fdn_farneback", "fdn_farneback_strided", "fdn_farneback_dev",
+    "fdn_warp", "fdn_warp_strided", "fdn_warp_dev",
     "fdn_filter_axis_dev", "fdn_filter_axis", "fdn_filter_3d_dev", "fdn_filter_3d",
     "fdn_mean_host", "fdn_mean_dev", "fdn_np_chunk_sums_dev", "fdn_sum_dev", "fdn_sweep_stack_dev", "fdn_permute_dev",
     "fdn_enable_timers", "fdn_get_timers", "fdn_version",
@@ -182,9 +183,18 @@ class Handle:
         return {n: (ms[i], cnt[i]) for i, n in enumerate(TIMER_NAMES)}
 
     # -- pair operators ------------------------------------------------------------
+    @staticmethod
+    def _view(img):
+        """(pointer, row stride, column stride) of a 2-D float32 view, strides in elements: no copy for the slice
+        views the reference passes (padded_vol[:, y + i, :], seq:255; padded_vol[:, :, x + i], seq:333)."""
+        img = np.asarray(img)
+        if img.dtype != np.float32 or img.ndim != 2 or img.strides[0] % 4 or img.strides[1] % 4:
+            img = np.ascontiguousarray(img, dtype=np.float32)      # other dtypes: converted (cv2 converts to f32 too)
+        return img, ctypes.c_void_p(img.ctypes.data), ctypes.c_ssize_t(img.strides[0] // 4), ctypes.c_ssize_t(img.strides[1] // 4)
+
     def farneback(self, prev, next, flow, levels, winsize, iters, poly_n, poly_sigma, flags):
-        prev = np.ascontiguousarray(prev, dtype=np.float32)
-        next = np.ascontiguousarray(next, dtype=np.float32)
+        prev, pp, prs, pcs = self._view(prev)
+        next, np_, nrs, ncs = self._view(next)
         H, W = prev.shape
         if next.shape != (H, W):
             raise ValueError("prev and next must have the same shape")
@@ -193,21 +203,33 @@ class Handle:
                 raise ValueError("USE_INITIAL_FLOW needs a contiguous (H, W, 2) float32 flow")
         else:
             flow = np.zeros((H, W, 2), dtype=np.float32)
-        check(self._lib.fdn_farneback(self._h, _ptr(prev), _ptr(next), _ptr(flow), ctypes.c_int(H), ctypes.c_int(W),
-                                      ctypes.c_int(int(levels)), ctypes.c_int(int(winsize)), ctypes.c_int(int(iters)),
-                                      ctypes.c_int(int(poly_n)), ctypes.c_double(float(poly_sigma)),
-                                      ctypes.c_int(int(flags))))
+        check(self._lib.fdn_farneback_strided(self._h, pp, prs, pcs, np_, nrs, ncs, _ptr(flow), ctypes.c_int(H), ctypes.c_int(W),
+                                              ctypes.c_int(int(levels)), ctypes.c_int(int(winsize)), ctypes.c_int(int(iters)),
+                                              ctypes.c_int(int(poly_n)), ctypes.c_double(float(poly_sigma)),
+                                              ctypes.c_int(int(flags))))
         return flow
 
     def warp(self, reference, flow):
-        reference = np.ascontiguousarray(reference, dtype=np.float32)
+        reference, rp, rs, cs = self._view(reference)
         flow = np.ascontiguousarray(flow, dtype=np.float32)
         H, W = flow.shape[:2]
         if reference.shape != (H, W) or flow.shape != (H, W, 2):
             raise ValueError("reference (H, W) and flow (H, W, 2) shapes disagree")
         dst = np.empty((H, W), dtype=np.float32)
-        check(self._lib.fdn_warp(self._h, _ptr(reference), _ptr(flow), _ptr(dst), ctypes.c_int(H), ctypes.c_int(W)))
+        check(self._lib.fdn_warp_strided(self._h, rp, rs, cs, _ptr(flow), _ptr(dst), ctypes.c_int(H), ctypes.c_int(W)))
         return dst
+
+    def farneback_dev(self, d_prev, prev_strides, d_next, next_strides, d_flow, H, W, levels, winsize, iters, poly_n, poly_sigma, flags):
+        """Device pointers; strides = (row, column) in elements; d_flow (H, W, 2) contiguous, updated in place."""
+        check(self._lib.fdn_farneback_dev(self._h, ctypes.c_void_p(d_prev), ctypes.c_ssize_t(prev_strides[0]), ctypes.c_ssize_t(prev_strides[1]),
+                                          ctypes.c_void_p(d_next), ctypes.c_ssize_t(next_strides[0]), ctypes.c_ssize_t(next_strides[1]),
+                                          ctypes.c_void_p(d_flow), ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(int(levels)),
+                                          ctypes.c_int(int(winsize)), ctypes.c_int(int(iters)), ctypes.c_int(int(poly_n)),
+                                          ctypes.c_double(float(poly_sigma)), ctypes.c_int(int(flags))))
+
+    def warp_dev(self, d_reference, strides, d_flow, d_dst, H, W):
+        check(self._lib.fdn_warp_dev(self._h, ctypes.c_void_p(d_reference), ctypes.c_ssize_t(strides[0]), ctypes.c_ssize_t(strides[1]),
+                                     ctypes.c_void_p(d_flow), ctypes.c_void_p(d_dst), ctypes.c_int(H), ctypes.c_int(W)))
 
     # -- volume operators ----------------------------------------------------------
     @staticmethod

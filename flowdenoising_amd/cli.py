@@ -92,11 +92,14 @@ def _run_single(args, vol, kernels, l, w, device):
     return filter_3d_own_mean(vol, kernels, params, device)   # mean = vol.mean() (seq:420), taken on the GPU
 
 
-def _run_sharded(args, vol, kernels, l, w):
-    """Called under torch.distributed.run: every rank reads its Z-slab, rank 0 writes."""
+def _run_sharded(args, shape, kernels, l, w):
+    """Called under torch.distributed.run (one rank per GPU).  Every rank reads ITS OWN Z-slab of the input file;
+    the global mean (seq:420) is assembled from the ranks' chunk sums (numpy's float32 value, bit for bit); the
+    filtered slabs are sent to rank 0 only, which writes the output."""
     import torch
     import torch.distributed as dist
     from . import _lib
+    from . import io as fio
     from .distributed import SlabEngine, SlabPlan
     from .operators import _params
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -104,25 +107,25 @@ def _run_sharded(args, vol, kernels, l, w):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist.init_process_group("nccl", device_id=dev)
-    plan = SlabPlan(vol.shape, world, rank)
-    slab = torch.from_numpy(np.ascontiguousarray(vol[plan.z0:plan.z0 + plan.zlen], dtype=np.float32)).to(dev)
+    plan = SlabPlan(shape, world, rank)
+    mine = np.ascontiguousarray(fio.read_slab(args.input, plan.z0, plan.z0 + plan.zlen), dtype=np.float32)   # seq:517
+    slab = torch.from_numpy(mine).to(dev)
     h = _lib.Handle(local)
     h.set_stream(torch.cuda.current_stream().cuda_stream)
     border = _lib.BORDER_WRAP if args.compat == "par" else _lib.BORDER_MEAN_PAD
     params = _params(l, w, use_of=not args.no_OF, border_mode=border, chained=not args.recompute_flow)
-    # seq:420 on the whole volume, numpy's own value: rank 0 computes it, everyone gets its bits
-    mt = torch.zeros(1, dtype=torch.float32, device=dev)
-    if rank == 0:
-        mt[0] = float(np.asarray(vol, dtype=np.float32).mean())
-    dist.broadcast(mt, src=0)
-    mean = np.float32(mt.item())
-    out = SlabEngine(plan, h, dist).filter_3d(slab, kernels, params, mean=mean)
-    parts = [torch.empty((e - s,) + tuple(vol.shape[1:]), dtype=torch.float32, device=dev) for s, e in plan.parts[0]]
-    for r, g in enumerate(parts):   # slabs may differ in length: one broadcast per owner
-        if r == rank:
-            g.copy_(out)
-        dist.broadcast(g, src=r)
-    res = torch.cat(parts).cpu().numpy() if rank == 0 else None
+    out = SlabEngine(plan, h, dist).filter_3d(slab, kernels, params)
+    res = None
+    if rank == 0:                       # slabs may differ in length: point-to-point into their place, rank 0 only
+        full = torch.empty(tuple(shape), dtype=torch.float32, device=dev)
+        full[plan.z0:plan.z0 + plan.zlen].copy_(out)
+        ops = [dist.P2POp(dist.irecv, full[s:e], r) for r, (s, e) in enumerate(plan.parts[0]) if r != 0]
+        for wk in (dist.batch_isend_irecv(ops) if ops else []):
+            wk.wait()
+        res = full.cpu().numpy()
+    else:
+        for wk in dist.batch_isend_irecv([dist.P2POp(dist.isend, out.contiguous(), 0)]):
+            wk.wait()
     dist.barrier()
     dist.destroy_process_group()
     return res
@@ -150,6 +153,9 @@ def main(argv=None):
         logging.info(f"Verbosity level = {args.verbosity}")
 
     sharded = "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if args.gpus > 1 and (args.chunk_slices or args.device):
+        parser.error("--gpus shards the volume over GPUs 0..N-1 and keeps every slab resident: "
+                     "it cannot be combined with --chunk_slices or --device")
     if args.gpus > 1 and not sharded:
         import subprocess
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -171,11 +177,16 @@ def main(argv=None):
     from .operators import get_gaussian_kernel
     logging.info(f"reading \"{args.input}\"")
     t0 = time.perf_counter()
-    vol = fio.read_volume(args.input, mmap=args.memory_map)
+    if sharded:                      # header only: every rank reads its own slab in _run_sharded
+        shape, dtype = fio.volume_info(args.input)
+        vol = None
+    else:
+        vol = fio.read_volume(args.input, mmap=args.memory_map)
+        shape, dtype = vol.shape, vol.dtype
     logging.info(f"read \"{args.input}\" in {time.perf_counter() - t0} seconds")
-    logging.info(f"shape of the input volume (Z, Y, X) = {vol.shape}")
-    logging.info(f"type of the volume = {vol.dtype}")
-    if rank == 0:
+    logging.info(f"shape of the input volume (Z, Y, X) = {shape}")
+    logging.info(f"type of the volume = {dtype}")
+    if vol is not None:
         logging.info(f"{args.input} max = {vol.max()}")
         logging.info(f"{args.input} min = {vol.min()}")
         logging.info(f"Input vol average = {vol.mean()}")
@@ -186,7 +197,7 @@ def main(argv=None):
     state["stage"] = "filtering"
     t0 = time.perf_counter()
     if sharded:
-        filtered = _run_sharded(args, vol, kernels, l, w)
+        filtered = _run_sharded(args, shape, kernels, l, w)
     else:
         filtered = _run_single(args, vol, kernels, l, w, args.device)
     logging.info(f"Volume filtered in {time.perf_counter() - t0} seconds")

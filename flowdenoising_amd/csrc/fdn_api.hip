@@ -152,7 +152,9 @@ struct fdn_ctx {
     hipStream_t stream = nullptr;
     size_t ws_limit = 0;
     Tuning tn;
-    DevBuf R, M0, M1, flow, stack, sweep_out, vol_a, vol_b, partials, pair;
+    DevBuf R, M0, M1, flow, stack, sweep_out, vol_a, vol_b, partials, pair, vol_in, vol_out;
+    void* pinned = nullptr;          // host staging of the pair-level entry points (hipHostMalloc)
+    size_t pinned_cap = 0;
     DevBuf Rpyr, flow_pyr, pyr_tmp, area_tab;   // pyramid levels >= 1
     struct AreaKey { int sh, sw, dh, dw; } area_key = {0, 0, 0, 0};
     struct AreaPtrs { const int *x_si, *x_start, *y_si, *y_start; const float *x_alpha, *y_alpha; } area = {};
@@ -198,6 +200,28 @@ static int ensure(fdn_ctx* h, DevBuf& b, size_t bytes)
     if (e != hipSuccess) { b.p = nullptr; return fail("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
     b.cap = bytes;
     return 0;
+}
+
+static int ensure_pinned(fdn_ctx* h, size_t bytes)
+{
+    if (h->pinned_cap >= bytes) return 0;
+    FDN_HIP(hipStreamSynchronize(h->stream));
+    if (h->pinned) { FDN_HIP(hipHostFree(h->pinned)); h->pinned = nullptr; h->pinned_cap = 0; }
+    hipError_t e = hipHostMalloc(&h->pinned, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { h->pinned = nullptr; return fail("hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
+    h->pinned_cap = bytes;
+    return 0;
+}
+
+// dst (contiguous H x W) <- the view src[r * rs + c * cs] of host memory
+static void gather_host(float* dst, const float* src, ptrdiff_t rs, ptrdiff_t cs, int H, int W)
+{
+    for (int r = 0; r < H; r++) {
+        const float* s = src + (ptrdiff_t)r * rs;
+        float* d = dst + (size_t)r * W;
+        if (cs == 1) memcpy(d, s, (size_t)W * sizeof(float));
+        else for (int c = 0; c < W; c++) d[c] = s[(ptrdiff_t)c * cs];
+    }
 }
 
 struct ScopedTimer {
@@ -744,8 +768,9 @@ FDN_API int fdn_destroy(fdn_handle h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     DevBuf* bufs[] = {&h->R, &h->M0, &h->M1, &h->flow, &h->stack, &h->sweep_out, &h->vol_a, &h->vol_b, &h->partials, &h->pair,
-                      &h->Rpyr, &h->flow_pyr, &h->pyr_tmp, &h->area_tab};
+                      &h->vol_in, &h->vol_out, &h->Rpyr, &h->flow_pyr, &h->pyr_tmp, &h->area_tab};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+    if (h->pinned) (void)hipHostFree(h->pinned);
     resolve_stamps(h);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -847,36 +872,14 @@ FDN_API int fdn_gaussian_kernel(double sigma, double* out, int cap)
     return K;
 }
 
-FDN_API int fdn_farneback(fdn_handle h, const float* prev, const float* next, float* flow_io, int H, int W,
-                          int levels, int winsize, int iters, int poly_n, double poly_sigma, int flags)
+// The pair-level Farneback on device data: img = [prev | next] contiguous H x W each, flow (H x W x 2) holds the
+// initial flow (or anything, without USE_INITIAL_FLOW) and receives the result; R, M0, M1 are scratch.
+static int farneback_pair_dev(fdn_ctx* h, float* img, float* R, float* flow, float* M0, float* M1, int H, int W,
+                              int levels, int winsize, int iters, int poly_n, double poly_sigma, int flags)
 {
-    FDN_ENTER(h);
-    if (!prev || !next || !flow_io) return fail("NULL image/flow pointer");
-    if (H < 2 || W < 2) return fail("optical flow needs images of at least 2x2 pixels, got %dx%d", W, H);
-    // the kernels address the pixels of one image by 32-bit byte offsets (8 bytes per pixel pair plane)
-    if (H >= (1 << 24) || W >= (1 << 24) || (size_t)H * W >= ((size_t)1 << 29))
-        return fail("images of %dx%d pixels are not supported (limit: 2^29 pixels per image)", W, H);
-    if (flags & ~FDN_USE_INITIAL_FLOW) return fail("unsupported flags 0x%x (only OPTFLOW_USE_INITIAL_FLOW)", flags);
-    fdn_sweep_params p{levels, winsize, iters, poly_n, poly_sigma, 0, 1, 1};
-    if (check_params(&p, 1)) return -1;
     std::vector<PyrLevel> lv = pyramid_levels(levels, H, W);
-    const size_t HW = (size_t)H * W;
     hipStream_t st = h->stream;
-    // pair scratch: [prev, next] images | R x2 | flow | M0 | M1
-    size_t need = HW * 4 * (2 + 10 + 2 + 5 + 5);
-    if (ensure(h, h->pair, need)) return -1;
-    float* img = (float*)h->pair.p;
-    float* R = img + 2 * HW;
-    float* flow = R + 10 * HW;
-    float* M0 = flow + 2 * HW;
-    float* M1 = M0 + 5 * HW;
-    {
-        ScopedTimer t(h, FDN_TIMER_TRANSFER);
-        FDN_HIP(hipMemcpyAsync(img, prev, HW * 4, hipMemcpyHostToDevice, st));
-        FDN_HIP(hipMemcpyAsync(img + HW, next, HW * 4, hipMemcpyHostToDevice, st));
-        if (flags & FDN_USE_INITIAL_FLOW) FDN_HIP(hipMemcpyAsync(flow, flow_io, HW * 8, hipMemcpyHostToDevice, st));
-        else launch_fill(flow, 0.f, HW * 2, st);
-    }
+    if (!(flags & FDN_USE_INITIAL_FLOW)) launch_fill(flow, 0.f, (size_t)H * W * 2, st);
     PolyConsts pc;
     prepare_poly_consts(poly_n, poly_sigma, &pc);
     {
@@ -889,33 +892,144 @@ FDN_API int fdn_farneback(fdn_handle h, const float* prev, const float* next, fl
         if (pyramid_batch(h, lv, R, flow, M0, M1, PairBatch{1, 0, 1}, H, W, winsize, iters, (flags & FDN_USE_INITIAL_FLOW) != 0)) return -1;
     } else if (run_iterations(h, R, flow, M0, M1, PairBatch{1, 0, 1}, H, W, winsize, iters)) return -1;
     FDN_HIP(hipGetLastError());
+    return 0;
+}
+
+static int check_pair_args(int H, int W, int levels, int winsize, int iters, int poly_n, double poly_sigma, int flags)
+{
+    if (H < 2 || W < 2) return fail("optical flow needs images of at least 2x2 pixels, got %dx%d", W, H);
+    // the kernels address the pixels of one image by 32-bit byte offsets (8 bytes per pixel pair plane)
+    if (H >= (1 << 24) || W >= (1 << 24) || (size_t)H * W >= ((size_t)1 << 29))
+        return fail("images of %dx%d pixels are not supported (limit: 2^29 pixels per image)", W, H);
+    if (flags & ~FDN_USE_INITIAL_FLOW) return fail("unsupported flags 0x%x (only OPTFLOW_USE_INITIAL_FLOW)", flags);
+    fdn_sweep_params p{levels, winsize, iters, poly_n, poly_sigma, 0, 1, 1};
+    return check_params(&p, 1);
+}
+
+// pair scratch: [prev, next] images | R x2 | flow | M0 | M1
+struct PairScratch { float *img, *R, *flow, *M0, *M1; };
+static int pair_scratch(fdn_ctx* h, int H, int W, PairScratch* ps)
+{
+    const size_t HW = (size_t)H * W;
+    if (ensure(h, h->pair, HW * 4 * (2 + 10 + 2 + 5 + 5))) return -1;
+    ps->img = (float*)h->pair.p;
+    ps->R = ps->img + 2 * HW;
+    ps->flow = ps->R + 10 * HW;
+    ps->M0 = ps->flow + 2 * HW;
+    ps->M1 = ps->M0 + 5 * HW;
+    return 0;
+}
+
+FDN_API int fdn_farneback_strided(fdn_handle h, const float* prev, ptrdiff_t prev_rs, ptrdiff_t prev_cs,
+                                  const float* next, ptrdiff_t next_rs, ptrdiff_t next_cs, float* flow_io, int H, int W,
+                                  int levels, int winsize, int iters, int poly_n, double poly_sigma, int flags)
+{
+    FDN_ENTER(h);
+    if (!prev || !next || !flow_io) return fail("NULL image/flow pointer");
+    if (check_pair_args(H, W, levels, winsize, iters, poly_n, poly_sigma, flags)) return -1;
+    const size_t HW = (size_t)H * W;
+    hipStream_t st = h->stream;
+    PairScratch ps;
+    if (pair_scratch(h, H, W, &ps)) return -1;
+    // host staging (pinned, owned by the handle): the two views gathered contiguously | the flow
+    if (ensure_pinned(h, HW * 4 * 4)) return -1;
+    float* stage = (float*)h->pinned;
     {
         ScopedTimer t(h, FDN_TIMER_TRANSFER);
-        FDN_HIP(hipMemcpyAsync(flow_io, flow, HW * 8, hipMemcpyDeviceToHost, st));
-        FDN_HIP(hipStreamSynchronize(st));
+        gather_host(stage, prev, prev_rs, prev_cs, H, W);
+        gather_host(stage + HW, next, next_rs, next_cs, H, W);
+        FDN_HIP(hipMemcpyAsync(ps.img, stage, HW * 8, hipMemcpyHostToDevice, st));
+        if (flags & FDN_USE_INITIAL_FLOW) {
+            memcpy(stage + 2 * HW, flow_io, HW * 8);
+            FDN_HIP(hipMemcpyAsync(ps.flow, stage + 2 * HW, HW * 8, hipMemcpyHostToDevice, st));
+        }
     }
+    if (farneback_pair_dev(h, ps.img, ps.R, ps.flow, ps.M0, ps.M1, H, W, levels, winsize, iters, poly_n, poly_sigma, flags)) return -1;
+    {
+        ScopedTimer t(h, FDN_TIMER_TRANSFER);
+        FDN_HIP(hipMemcpyAsync(stage + 2 * HW, ps.flow, HW * 8, hipMemcpyDeviceToHost, st));
+        FDN_HIP(hipStreamSynchronize(st));
+        memcpy(flow_io, stage + 2 * HW, HW * 8);
+    }
+    return 0;
+}
+
+FDN_API int fdn_farneback(fdn_handle h, const float* prev, const float* next, float* flow_io, int H, int W,
+                          int levels, int winsize, int iters, int poly_n, double poly_sigma, int flags)
+{
+    return fdn_farneback_strided(h, prev, W, 1, next, W, 1, flow_io, H, W, levels, winsize, iters, poly_n, poly_sigma, flags);
+}
+
+FDN_API int fdn_farneback_dev(fdn_handle h, const float* d_prev, ptrdiff_t prev_rs, ptrdiff_t prev_cs,
+                              const float* d_next, ptrdiff_t next_rs, ptrdiff_t next_cs, float* d_flow_io, int H, int W,
+                              int levels, int winsize, int iters, int poly_n, double poly_sigma, int flags)
+{
+    FDN_ENTER(h);
+    if (!d_prev || !d_next || !d_flow_io) return fail("NULL image/flow pointer");
+    if (check_pair_args(H, W, levels, winsize, iters, poly_n, poly_sigma, flags)) return -1;
+    PairScratch ps;
+    if (pair_scratch(h, H, W, &ps)) return -1;
+    const size_t HW = (size_t)H * W;
+    launch_copy_strided(d_prev, prev_rs, prev_cs, ps.img, H, W, h->stream);
+    launch_copy_strided(d_next, next_rs, next_cs, ps.img + HW, H, W, h->stream);
+    // the caller's flow buffer is used in place (cv2 updates `flow` in place too, seq:98)
+    return farneback_pair_dev(h, ps.img, ps.R, d_flow_io, ps.M0, ps.M1, H, W, levels, winsize, iters, poly_n, poly_sigma, flags);
+}
+
+static int check_warp_args(const void* a, const void* b, const void* c, int H, int W)
+{
+    if (!a || !b || !c) return fail("NULL pointer");
+    if (H <= 0 || W <= 0) return fail("bad image dims");
+    if (H >= (1 << 24) || W >= (1 << 24) || (size_t)H * W >= ((size_t)1 << 29))
+        return fail("images of %dx%d pixels are not supported (limit: 2^29 pixels per image)", W, H);
+    return 0;
+}
+
+FDN_API int fdn_warp_strided(fdn_handle h, const float* reference, ptrdiff_t rs, ptrdiff_t cs, const float* flow, float* dst, int H, int W)
+{
+    FDN_ENTER(h);
+    if (check_warp_args(reference, flow, dst, H, W)) return -1;
+    const size_t HW = (size_t)H * W;
+    hipStream_t st = h->stream;
+    if (ensure(h, h->pair, HW * 4 * 4)) return -1;
+    if (ensure_pinned(h, HW * 4 * 4)) return -1;
+    float* d_src = (float*)h->pair.p;
+    float* d_flow = d_src + HW;
+    float* d_dst = d_flow + 2 * HW;
+    float* stage = (float*)h->pinned;
+    {
+        ScopedTimer t(h, FDN_TIMER_TRANSFER);
+        gather_host(stage, reference, rs, cs, H, W);
+        memcpy(stage + HW, flow, HW * 8);
+        FDN_HIP(hipMemcpyAsync(d_src, stage, HW * 12, hipMemcpyHostToDevice, st));
+    }
+    launch_warp(d_src, d_flow, d_dst, H, W, st);
+    FDN_HIP(hipGetLastError());
+    ScopedTimer t(h, FDN_TIMER_TRANSFER);
+    FDN_HIP(hipMemcpyAsync(stage + 3 * HW, d_dst, HW * 4, hipMemcpyDeviceToHost, st));
+    FDN_HIP(hipStreamSynchronize(st));
+    memcpy(dst, stage + 3 * HW, HW * 4);
     return 0;
 }
 
 FDN_API int fdn_warp(fdn_handle h, const float* reference, const float* flow, float* dst, int H, int W)
 {
+    return fdn_warp_strided(h, reference, W, 1, flow, dst, H, W);
+}
+
+FDN_API int fdn_warp_dev(fdn_handle h, const float* d_reference, ptrdiff_t rs, ptrdiff_t cs, const float* d_flow, float* d_dst, int H, int W)
+{
     FDN_ENTER(h);
-    if (!reference || !flow || !dst) return fail("NULL pointer");
-    if (H <= 0 || W <= 0) return fail("bad image dims");
-    if (H >= (1 << 24) || W >= (1 << 24) || (size_t)H * W >= ((size_t)1 << 29))
-        return fail("images of %dx%d pixels are not supported (limit: 2^29 pixels per image)", W, H);
-    const size_t HW = (size_t)H * W;
-    hipStream_t st = h->stream;
-    if (ensure(h, h->pair, HW * 4 * 4)) return -1;
-    float* d_src = (float*)h->pair.p;
-    float* d_flow = d_src + HW;
-    float* d_dst = d_flow + 2 * HW;
-    FDN_HIP(hipMemcpyAsync(d_src, reference, HW * 4, hipMemcpyHostToDevice, st));
-    FDN_HIP(hipMemcpyAsync(d_flow, flow, HW * 8, hipMemcpyHostToDevice, st));
-    launch_warp(d_src, d_flow, d_dst, H, W, st);
+    if (check_warp_args(d_reference, d_flow, d_dst, H, W)) return -1;
+    const float* src = d_reference;
+    if (rs != W || cs != 1) {
+        if (ensure(h, h->pair, (size_t)H * W * 4)) return -1;
+        launch_copy_strided(d_reference, rs, cs, (float*)h->pair.p, H, W, h->stream);
+        src = (const float*)h->pair.p;
+    }
+    if (src == d_dst) return fail("reference and dst must not alias");
+    launch_warp(src, d_flow, d_dst, H, W, h->stream);
     FDN_HIP(hipGetLastError());
-    FDN_HIP(hipMemcpyAsync(dst, d_dst, HW * 4, hipMemcpyDeviceToHost, st));
-    FDN_HIP(hipStreamSynchronize(st));
     return 0;
 }
 
@@ -963,31 +1077,43 @@ FDN_API int fdn_filter_axis(fdn_handle h, const float* in, float* out, int Z, in
     return 0;
 }
 
+// Page-lock the caller's buffer for the duration of a call so that the copy is one DMA at PCIe speed instead of
+// the runtime's staged pageable copy; when the registration is refused (already registered, locked-memory limit)
+// the pageable path still works.
+struct ScopedHostRegister {
+    void* p = nullptr;
+    ScopedHostRegister(const void* ptr, size_t bytes)
+    {
+        if (bytes >= ((size_t)8 << 20) && hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) p = const_cast<void*>(ptr);
+        else (void)hipGetLastError();
+    }
+    ~ScopedHostRegister() { if (p) (void)hipHostUnregister(p); }
+};
+
 FDN_API int fdn_filter_3d(fdn_handle h, const float* in, float* out, int Z, int Y, int X,
                           const double* const kernels[3], const int K[3], float pad_value, const fdn_sweep_params* p)
 {
     FDN_ENTER(h);
     if (!in || !out) return fail("NULL pointer");
     if (Z <= 0 || Y <= 0 || X <= 0) return fail("bad volume dims");
-    size_t count = (size_t)Z * Y * X;
-    void *d_in = nullptr, *d_out = nullptr;
-    FDN_HIP(hipMalloc(&d_in, count * sizeof(float)));
-    hipError_t e = hipMalloc(&d_out, count * sizeof(float));
-    if (e != hipSuccess) { (void)hipFree(d_in); return fail("hipMalloc failed: %s", hipGetErrorString(e)); }
-    int rc = 0;
+    const size_t bytes = (size_t)Z * Y * X * sizeof(float);
+    // device copies of the volume live in the handle and are reused by the next call
+    if (ensure(h, h->vol_in, bytes) || ensure(h, h->vol_out, bytes)) return -1;
+    ScopedHostRegister rin(in, bytes), rout(out, bytes);
     {
         ScopedTimer t(h, FDN_TIMER_TRANSFER);
-        if (hipMemcpyAsync(d_in, in, count * sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = fail("H2D failed");
+        FDN_HIP(hipMemcpyAsync(h->vol_in.p, in, bytes, hipMemcpyHostToDevice, h->stream));
     }
-    if (!rc) rc = filter_3d_dev(h, (const float*)d_in, (float*)d_out, Z, Y, X, kernels, K, pad_value, p);
-    if (!rc) {
+    if (filter_3d_dev(h, (const float*)h->vol_in.p, (float*)h->vol_out.p, Z, Y, X, kernels, K, pad_value, p)) {
+        (void)hipStreamSynchronize(h->stream);
+        return -1;
+    }
+    {
         ScopedTimer t(h, FDN_TIMER_TRANSFER);
-        if (hipMemcpyAsync(out, d_out, count * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = fail("D2H failed");
+        FDN_HIP(hipMemcpyAsync(out, h->vol_out.p, bytes, hipMemcpyDeviceToHost, h->stream));
     }
-    (void)hipStreamSynchronize(h->stream);
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
-    return rc;
+    FDN_HIP(hipStreamSynchronize(h->stream));
+    return 0;
 }
 
 FDN_API int fdn_sum_dev(fdn_handle h, const float* d_in, size_t count, double* sum_out)
@@ -1027,13 +1153,6 @@ FDN_API int fdn_np_chunk_sums_dev(fdn_handle h, const float* d_in, size_t count,
     if (!d_in || !sums_out) return fail("NULL pointer");
     if (!count) return fail("empty volume");
     size_t full = count / 8192, rest = count % 8192;
-    if ((uintptr_t)d_in & 15) {       // the kernel reads float4: an unaligned view is reduced on the host
-        std::vector<float> all(count);
-        FDN_HIP(hipMemcpyAsync(all.data(), d_in, count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        FDN_HIP(hipStreamSynchronize(h->stream));
-        for (size_t c = 0; c * 8192 < count; c++) sums_out[c] = np_pairwise_sum_f32(all.data() + c * 8192, std::min<size_t>(8192, count - c * 8192));
-        return 0;
-    }
     if (full) {
         if (ensure(h, h->partials, full * sizeof(float))) return -1;
         launch_np_chunk_sums(d_in, full, (float*)h->partials.p, h->stream);

@@ -98,6 +98,8 @@ int launch_farneback_iter(const float* Rstack, const float* stack, const float* 
 struct FlowSource { int h, w; double sx, sy; };   // h == 0: flow_in has the image's own size
 
 void launch_fill(float* dst, float value, size_t count, hipStream_t st);
+// out[r][c] (contiguous H x W) = in[r * rs + c * cs]  (strides in elements; a slice view of a volume)
+void launch_copy_strided(const float* in, int64_t rs, int64_t cs, float* out, int H, int W, hipStream_t st);
 void launch_permute(const float* in, float* out, int A, int B, int C, int64_t sa, int64_t sb,
                     int64_t sc, hipStream_t st);
 // partial sums (f64) into `partials` (nblocks entries); returns nblocks used

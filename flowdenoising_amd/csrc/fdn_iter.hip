@@ -14,12 +14,12 @@
 //   wave 0 (producer)  row t         : M row from flow_in, R0 and the bilinear gather of R1 -> LDS ring slot t % RS
 //   wave 1 (consumer)  row t - MH - 1: OpenCV's vertical running sum vsum += f32(M[y+MH] - M[y-MH-1]) (carried in
 //                                      registers from row 0: the f32-fed recurrence is what makes results bit-faithful,
-//                                      DESIGN.md 3.2), horizontal window across lanes through a per-wave LDS row,
+//                                      DESIGN.md 3.2), horizontal window across lanes by doubling through LDS rows,
 //                                      2 x 2 solve, store; on the last iteration of level 0 the 1/32-px remap of the
 //                                      neighbour and acc = f32(f64(acc) + f64(v) w) (seq:106-107)
 //   one s_barrier per row step; the ring holds rows t - 2 MH - 2 .. t (RS = 2 MH + 3 rows x 1280 B): what the
 //   producer writes in step t nobody reads in step t.
-// LDS per workgroup at winsize 15: 21.8 KB ring + 3.1 KB window row = 24.9 KB -> 6 workgroups = 12 waves per CU.
+// LDS per workgroup at winsize 15: 21.8 KB ring + 6.4 KB doubling rows = 28.2 KB -> 5 workgroups = 10 waves per CU.
 #include "fdn_internal.h"
 #include "fdn_device.h"
 
@@ -45,8 +45,8 @@ __global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // ring row: [ (m0, m2) x 64 ][ (m3, m4) x 64 ][ m1 x 64 ] floats; then the consumer's window row: 5 x (64 + 2 MH) doubles
     float* ring = lds;
-    double* xch = (double*)(lds + (size_t)RS * 320);
-    const int XP = 64 + 2 * MH;
+    double* xch = (double*)(lds + (size_t)RS * 320);      // [2][5][XP]: the doubling rows (see the consumer)
+    const int XP = 64 + 2 * MH + 2;                       // MH columns of padding on the left, MH + 1 (+1: even) on the right
 
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -79,39 +79,48 @@ __global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict_
         const float bxx = border_factor(xc, W);
         const bool xdamp = border_test(xc, W);
         const float xf = (float)xc;
-        // operands of row 0; inside the loop always one row ahead, the gather of row t + 1 issued before row t is finished
-        float2 fA = load_flow(0);
-        fdn_v2f a01, a23; float a4;
-        load_R(R0i, (unsigned)xc, a01, a23, a4);
-        int x1A, y1A; float fxA, fyA;
-        flow_target(xf, 0.f, fA.x, fA.y, x1A, y1A, fxA, fyA);
-        GatherTapsP gA;
-        gather_R1_p(R1i, H, W, x1A, y1A, gA);
+        // Operands of a row arrive in two dependent hops: its flow and R0, then -- at the position the flow points to --
+        // the bilinear footprint of R1.  Three register sets rotate (the loop is unrolled by three) so that neither
+        // hop is waited for in the step that issues it: step t loads flow/R0 of row t + 2, issues the gather of row
+        // t + 1 (whose flow was loaded a step earlier) and turns row t into M.  (A register copy at the end of a step
+        // would make the wave wait for the loads right away.)
+        struct RowOps { float2 f; fdn_v2f r01, r23; float r4; int x1, y1; float fx, fy; GatherTapsP g; };
+        auto load_ops = [&](int row, RowOps& o) __attribute__((always_inline)) {
+            row = row < H ? row : H - 1;
+            o.f = load_flow(row);
+            load_R(R0i, (unsigned)row * (unsigned)W + (unsigned)xc, o.r01, o.r23, o.r4);
+        };
+        auto gather_ops = [&](int row, RowOps& o) __attribute__((always_inline)) {
+            row = row < H ? row : H - 1;
+            flow_target(xf, (float)row, o.f.x, o.f.y, o.x1, o.y1, o.fx, o.fy);
+            gather_R1_p(R1i, H, W, o.x1, o.y1, o.g);
+        };
         int slot = 0;
-        for (int t = 0; t < T; t++) {
+        auto step = [&](int t, const RowOps& cur, RowOps& mid, RowOps& far) __attribute__((always_inline)) {
             if (t < H) {
-                // row t + 1: operands and gather in flight while row t is turned into M
-                const int tn = t + 1 < H ? t + 1 : H - 1;
-                const float2 fB = load_flow(tn);
-                fdn_v2f b01, b23; float b4;
-                load_R(R0i, (unsigned)tn * (unsigned)W + (unsigned)xc, b01, b23, b4);
-                int x1B, y1B; float fxB, fyB;
-                flow_target(xf, (float)tn, fB.x, fB.y, x1B, y1B, fxB, fyB);
-                GatherTapsP gB;
-                gather_R1_p(R1i, H, W, x1B, y1B, gB);
-
+                load_ops(t + 2, far);
+                gather_ops(t + 1, mid);
                 const float by0 = t < 5 ? (t < 2 ? 0.14f : 0.4472f) : 1.f;
                 const float by1 = t >= H - 5 ? (H - t - 1 < 2 ? 0.14f : 0.4472f) : 1.f;
                 fdn_v2f m02, m34; float m1;
-                finish_M_p(a01, a23, a4, gA, H, W, x1A, y1A, fxA, fyA, fA.x, fA.y, bxx, by0, by1, xdamp || border_test(t, H), m02, m1, m34);
+                finish_M_p(cur.r01, cur.r23, cur.r4, cur.g, H, W, cur.x1, cur.y1, cur.fx, cur.fy, cur.f.x, cur.f.y, bxx, by0, by1,
+                           xdamp || border_test(t, H), m02, m1, m34);
                 float* row = ring + (size_t)slot * 320;
                 *(fdn_v2f*)(row + 2 * lane) = m02;
                 *(fdn_v2f*)(row + 128 + 2 * lane) = m34;
                 row[256 + lane] = m1;
                 slot = slot + 1 == RS ? 0 : slot + 1;
-                fA = fB; a01 = b01; a23 = b23; a4 = b4; x1A = x1B; y1A = y1B; fxA = fxB; fyA = fyB; gA = gB;
             }
             lds_barrier_iter();
+        };
+        RowOps P0, P1, P2;
+        load_ops(0, P0);
+        load_ops(1, P1);
+        gather_ops(0, P0);
+        for (int t = 0; t < T; t += 3) {
+            step(t, P0, P1, P2);
+            if (t + 1 < T) step(t + 1, P1, P2, P0);
+            if (t + 2 < T) step(t + 2, P2, P0, P1);
         }
         return;
     }
@@ -147,29 +156,42 @@ __global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict_
             ring_row(y + MH < H - 1 ? y + MH : H - 1, lead);
             ring_row(y - MH - 1 > 0 ? y - MH - 1 : 0, trail);
 #pragma unroll
-            for (int c = 0; c < 5; c++) {
-                vs[c] += (double)(lead[c] - trail[c]);
-                xch[c * XP + lane + MH] = vs[c];
-            }
-            // only this wave reads what it wrote and a wave's LDS operations execute in order; the fences keep the
-            // compiler from moving the reads across the writes (other lanes' addresses)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            double a[5];
+            for (int c = 0; c < 5; c++) vs[c] += (double)(lead[c] - trail[c]);
+            // Horizontal window of 2 MH + 1 columns by doubling: T1 = vsum, T2k[L] = Tk[L] + Tk[L + k] (the sum of 2k
+            // columns starting at L); the window is the sum of the Tk of its binary digits, lowest first:
+            // winsize 15: v[L+7] + T2[L+5] + T4[L+1] + T8[L-7].  6 additions and 11 LDS accesses per channel where the
+            // plain window takes 14 and 16 (and 150 registers when unrolled).  Two LDS rows per channel, recycled:
+            // a wave's LDS operations execute in order, so a row may be rewritten once the reads of its previous
+            // content have been issued; the fences only keep the compiler from reordering across them.
+            // (Splitting the row into pipeline stages over consecutive steps -- window sums, solve + tap issue,
+            // weighting -- measured 6 % slower: the step is not bound by this chain.)
+            double a[5], tk[5];
 #pragma unroll
-            for (int c = 0; c < 5; c++) {
-                const double* w = xch + c * XP + lane;
-                double s = w[0];                  // the 2 MH + 1 terms left to right, starting from the first
-                if (MHT) {
+            for (int c = 0; c < 5; c++) tk[c] = vs[c];
+            int pos = MH;                       // column offset of the next term, counted down from the window's right end
+            bool first = true;
+            for (int k = 1, lvl = 0; k <= 2 * MH + 1; k <<= 1, lvl++) {
+                double* row = xch + (size_t)(lvl & 1) * 5 * XP;
 #pragma unroll
-                    for (int k = 1; k <= 2 * MHT; k++) s += w[k];
-                } else {
-                    for (int k = 1; k <= 2 * MH; k++) s += w[k];
+                for (int c = 0; c < 5; c++) row[c * XP + lane + MH] = tk[c];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const bool digit = ((2 * MH + 1) & k) != 0;
+                const bool more = 2 * k <= 2 * MH + 1;
+                if (digit) pos -= k;            // this digit's block starts at column offset pos + 1
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    const double* r = row + c * XP + lane + MH;
+                    if (digit) {
+                        const double term = r[pos + 1];
+                        a[c] = first ? term : a[c] + term;
+                    }
+                    if (more) tk[c] = tk[c] + r[k];
                 }
-                a[c] = s;
+                if (digit) first = false;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
             const float2 f = solve_flow(a, scale);
             if (ACC) {
                 const float warped = remap_sample(img1, H, W, xc, y, f);
@@ -193,7 +215,7 @@ bool iter_supported(int winsize, int H, int W)
     return mh >= 1 && mh <= 24 && H >= 2 && W >= 2 && H < (1 << 24) && W < (1 << 24) && (size_t)H * W < ((size_t)1 << 29);
 }
 
-size_t iter_lds_bytes(int mh) { return (size_t)(2 * mh + 3) * 320 * sizeof(float) + (size_t)5 * (64 + 2 * mh) * sizeof(double); }
+size_t iter_lds_bytes(int mh) { return (size_t)(2 * mh + 3) * 320 * sizeof(float) + (size_t)2 * 5 * (64 + 2 * mh + 2) * sizeof(double); }
 
 template <int MHT>
 static int launch_iter_t(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc, PairBatch pb,

@@ -517,6 +517,19 @@ void launch_fill(float* dst, float value, size_t count, hipStream_t st)
     hipLaunchKernelGGL(k_fill, dim3((unsigned)g), dim3(256), 0, st, dst, value, count);
 }
 
+// one image given as a strided view (the pair-level entry points; the sweeps re-orient whole volumes with the
+// tiled permute below instead)
+__global__ __launch_bounds__(256) void k_copy_strided(const float* __restrict__ in, int64_t rs, int64_t cs, float* __restrict__ out, int H, int W)
+{
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < W && y < H) out[(size_t)y * W + x] = in[(int64_t)y * rs + (int64_t)x * cs];
+}
+void launch_copy_strided(const float* in, int64_t rs, int64_t cs, float* out, int H, int W, hipStream_t st)
+{
+    if (H <= 0 || W <= 0) return;
+    hipLaunchKernelGGL(k_copy_strided, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, st, in, rs, cs, out, H, W);
+}
+
 // ---------------------------------------------------------------------------------
 // permute: out[a][b][c] = in[a*sa + b*sb + c*sc], out contiguous (A,B,C).
 // sc == 1: row copies.  Otherwise a 32x32 LDS-tiled transpose over the out dims
@@ -587,17 +600,23 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ 
 // recursion halves 8192 down to 64 leaves of 128 elements; a leaf is 8 interleaved accumulators over its
 // 16 groups of 8, combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); leaves combine left + right up the tree.
 // One wave per chunk, one lane per leaf.
+// ALIGNED: `in` is 16-byte aligned (float4 loads); otherwise dword loads (a slab view that starts mid-chunk)
+template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_np_chunk_sums(const float* __restrict__ in, size_t nchunks, float* __restrict__ sums)
 {
     const size_t chunk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (chunk >= nchunks) return;
     const int lane = threadIdx.x & 63;
-    const float4* a = (const float4*)(in + chunk * 8192 + (size_t)lane * 128);
-    float4 lo = a[0], hi = a[1];
+    const float* base = in + chunk * 8192 + (size_t)lane * 128;
+    auto ld4 = [&](int q) -> float4 {
+        if (ALIGNED) return ((const float4*)base)[q];
+        return make_float4(base[4 * q], base[4 * q + 1], base[4 * q + 2], base[4 * q + 3]);
+    };
+    float4 lo = ld4(0), hi = ld4(1);
     float r[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
     for (int i = 1; i < 16; i++) {
-        lo = a[2 * i]; hi = a[2 * i + 1];
+        lo = ld4(2 * i); hi = ld4(2 * i + 1);
         r[0] += lo.x; r[1] += lo.y; r[2] += lo.z; r[3] += lo.w;
         r[4] += hi.x; r[5] += hi.y; r[6] += hi.z; r[7] += hi.w;
     }
@@ -609,7 +628,8 @@ __global__ __launch_bounds__(256) void k_np_chunk_sums(const float* __restrict__
 void launch_np_chunk_sums(const float* in, size_t nchunks, float* sums, hipStream_t st)
 {
     if (!nchunks) return;
-    hipLaunchKernelGGL(k_np_chunk_sums, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, st, in, nchunks, sums);
+    if (((uintptr_t)in & 15) == 0) hipLaunchKernelGGL(k_np_chunk_sums<true>, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, st, in, nchunks, sums);
+    else hipLaunchKernelGGL(k_np_chunk_sums<false>, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, st, in, nchunks, sums);
 }
 
 int launch_sum_partials(const float* in, size_t count, double* partials, int max_blocks, hipStream_t st)

@@ -3,24 +3,36 @@
 Every axis pass shards along ITS OWN axis (target slices are independent; each needs K//2
 neighbour slices either side), so the volume moves through three partitions:
 
-    Z-slabs --Z pass--> Z-slabs --all-to-all--> Y-slabs --Y pass--> --all-to-all--> X-slabs
-            --X pass--> --all-to-all--> Z-slabs (output, same partition as the input)
+    Z-slabs --Z pass--> Z-slabs --exchange--> Y-slabs --Y pass--> --exchange--> X-slabs
+            --X pass--> --exchange--> Z-slabs (output, same partition as the input)
 
-with a K//2-slice halo exchange between neighbouring ranks before each pass (the outermost
-slabs pad with the global mean, src/flowdenoising_sequential.py:88, obtained by one scalar
-all-reduce, seq:420; wrap-around borders of src/flowdenoising.py:312 come from the far ranks).
 The Y/X passes cannot use fixed halos along Z because their images span Z (seq:255, seq:333),
-hence the repartition.
+hence the repartition.  ONE exchange per pass delivers both the new partition and its halos:
+rank i sends rank j the part of j's halo-extended range that i holds (for the Z pass: the
+K//2 boundary slices of the neighbouring slabs; for Y and X: an all-to-all of
+(own range) x (j's range + halo) blocks), so a pass costs one round of point-to-point
+messages and no second synchronisation for halos.  Slices outside the volume are filled
+with the global mean (src/flowdenoising_sequential.py:88; one small gather, seq:420) or come
+from the far ranks (wrap-around, src/flowdenoising.py:312).
 
 Collectives go through torch.distributed point-to-point ops (backend "nccl" = RCCL over xGMI on
-the GPU box, "gloo" in the CPU tests): they are neighbour / all-pairs exchanges of contiguous
-blocks, all links busy at once, no ring collective and no reduction of bulk data.
+the GPU box, "gloo" in the CPU tests): one batched group per exchange, all pairs at once -- all
+links busy, no ring, no reduction of bulk data.  The exchange stays on this side of the C ABI
+(INTEGRATION.md 3): libflowdn.so is single-device; it supplies the pass (fdn_sweep_stack_dev),
+the pack kernel (fdn_permute_dev) and the reduction pieces of the mean.
+
+Buffers (stack, pass output, send and receive staging) are allocated once per engine and reused
+every step.  Blocks are packed on the sender INTO THE RECEIVER'S ORIENTATION by the LDS-tiled
+permute kernel; the receiver drops them into its stack with row-contiguous strided copies.
 
 The compute of a pass is delegated to a backend object:
     backend.sweep_stack(stack, out, S, H, W, kernel, params)   stack: (S + 2r, H, W) tensor
-    backend.local_sum(tensor) -> float
-HipBackend (below) runs it in libflowdn.so; the CPU tests inject a backend built on the oracle.
+    backend.pack(src_view, dst)                                dst contiguous <- permuted/strided view
+    backend.chunk_sums(flat_tensor) -> float32 array           numpy's pairwise sums of 8192-element chunks
+HipBackend (below) runs them in libflowdn.so; the CPU tests inject a backend built on the oracle.
 """
+import time
+
 import numpy as np
 
 
@@ -33,6 +45,10 @@ def split(n, parts):
         out.append((s, e))
         s = e
     return out
+
+
+# orientation of a slab partitioned along `axis`: stack dims (slices, H, W) as global axes
+ORIENT = {0: (0, 1, 2), 1: (1, 0, 2), 2: (2, 0, 1)}  # Z: (z|y,x)  Y: (y|z,x)  X: (x|z,y)
 
 
 class SlabPlan:
@@ -52,34 +68,64 @@ class SlabPlan:
                 return r
         raise IndexError(idx)
 
-    def halo_runs(self, axis, r, wrap):
-        """Runs (src_rank, dst_rank, src_local_start, dst_stack_start, count) that fill every rank's
-        two halos of `r` slices along `axis`.  Stack position p of rank d holds global slice
-        start_d - r + p.  Mean-padded borders (wrap=False) produce no run for out-of-range slices."""
+    def stack_runs(self, axis, j, r, wrap):
+        """Rank j's stack along `axis` holds positions p = 0 .. len_j + 2r - 1, position p being global slice
+        s_j - r + p.  Returns maximal runs (p0, g0, count) of consecutive positions whose global slices are
+        consecutive and inside the volume (wrap: taken modulo the axis length); positions outside the volume
+        of a mean-padded pass belong to no run."""
         n = self.shape[axis]
+        s, e = self.parts[axis][j]
+        runs = []
+        for p in range(e - s + 2 * r):
+            g = s - r + p
+            if wrap:
+                g %= n
+            elif g < 0 or g >= n:
+                continue
+            if runs and runs[-1][0] + runs[-1][2] == p and runs[-1][1] + runs[-1][2] == g:
+                runs[-1][2] += 1
+            else:
+                runs.append([p, g, 1])
+        return [tuple(x) for x in runs]
+
+    def blocks(self, A, B, r, wrap, i, j):
+        """What rank i (holding its slab of the partition along A) sends rank j for the pass along B:
+        [(p0, {axis: (lo, hi)})] -- global index ranges of the block and the stack position of its first
+        B-slice.  Sender and receiver derive the same list, in the same order."""
+        si, ei = self.parts[A][i]
+        out = []
+        for p0, g0, cnt in self.stack_runs(B, j, r, wrap):
+            rng = {ax: (0, self.shape[ax]) for ax in range(3)}
+            if A == B:                     # same partition: i contributes the slices of the run it owns
+                lo, hi = max(g0, si), min(g0 + cnt, ei)
+                if lo >= hi:
+                    continue
+                rng[B] = (lo, hi)
+                out.append((p0 + lo - g0, rng))
+            else:                          # repartition: i holds every B-slice of its own A-range
+                rng[B] = (g0, g0 + cnt)
+                rng[A] = (si, ei)
+                out.append((p0, rng))
+        return out
+
+    # kept for callers of the round-1 interface (tests of the halo geometry)
+    def halo_runs(self, axis, r, wrap):
+        """Runs (src_rank, dst_rank, src_local_start, dst_stack_start, count) filling every rank's two halos."""
         runs = []
         for d, (s, e) in enumerate(self.parts[axis]):
-            for lo_p, lo_g in ((0, s - r), (r + (e - s), e)):
-                q = 0
-                while q < r:
-                    g = lo_g + q
-                    if wrap:
-                        g %= n
-                    elif g < 0 or g >= n:
-                        q += 1
+            for p0, g0, cnt in self.stack_runs(axis, d, r, wrap):
+                for q in range(cnt):
+                    p, g = p0 + q, g0 + q
+                    if r <= p < r + (e - s):
                         continue
                     src = self.owner(axis, g)
-                    ss, se = self.parts[axis][src]
-                    cnt = 1  # extend the run while contiguous, same owner and in range
-                    while q + cnt < r:
-                        g2 = lo_g + q + cnt
-                        g2 = g2 % n if wrap else g2
-                        if not (0 <= g2 < n) or g2 != g + cnt or not (ss <= g2 < se):
-                            break
-                        cnt += 1
-                    runs.append((src, d, g - ss, lo_p + q, cnt))
-                    q += cnt
-        return runs
+                    ss = self.parts[axis][src][0]
+                    last = runs[-1] if runs else None
+                    if last and last[0] == src and last[1] == d and last[2] + last[4] == g - ss and last[3] + last[4] == p:
+                        last[4] += 1
+                    else:
+                        runs.append([src, d, g - ss, p, 1])
+        return [tuple(x) for x in runs]
 
 
 class HipBackend:
@@ -92,6 +138,17 @@ class HipBackend:
         assert stack.is_contiguous() and out.is_contiguous()
         self.h.sweep_stack_dev(stack.data_ptr(), out.data_ptr(), S, H, W, kernel, params)
 
+    def pack(self, src_view, dst):
+        """dst (contiguous, same shape) <- src_view (a permuted / sliced view with one unit stride): fdn_permute_dev,
+        LDS-tiled so that both sides stay coalesced."""
+        st = src_view.stride()
+        if dst.numel() == 0:
+            return
+        if 1 not in st:                       # a one-element dim carries an arbitrary stride: let torch copy
+            dst.copy_(src_view)
+            return
+        self.h.permute_dev(src_view.data_ptr(), dst.data_ptr(), tuple(src_view.shape), tuple(st))
+
     def local_sum(self, t):
         return self.h.sum_dev(t.data_ptr(), t.numel())
 
@@ -103,8 +160,8 @@ class SlabEngine:
     """Distributed OF_filter / no_OF_filter on Z-slabs.  `dist` is torch.distributed (or None for a
     single rank).  Tensors live wherever the backend computes (CUDA for HipBackend)."""
 
-    # orientation of a slab partitioned along `axis`: stack dims (slices, H, W) as global axes
-    ORIENT = {0: (0, 1, 2), 1: (1, 0, 2), 2: (2, 0, 1)}  # Z: (z|y,x)  Y: (y|z,x)  X: (x|z,y)
+    ORIENT = ORIENT
+    PHASES = ("compute", "pack", "exchange", "unpack", "mean")
 
     def __init__(self, plan, backend, dist=None):
         import torch
@@ -112,115 +169,226 @@ class SlabEngine:
         self.plan, self.backend, self.dist = plan, backend, dist
         if hasattr(backend, "sweep_stack_dev"):  # a bare fdn handle was passed
             self.backend = HipBackend(backend)
+        self._bufs = {}
+        self._sched = {}
+        self._ms = {p: 0.0 for p in self.PHASES}
+        self._pending = []          # (phase, start event, stop event) not yet resolved
+        self.timing = True
 
-    # -- communication helpers -----------------------------------------------------------
-    def _exchange(self, sends, recvs):
-        """sends: [(dst_rank, tensor)], recvs: [(src_rank, tensor)] in matching per-pair order.
-        Self-pairs are copied locally."""
-        torch, dist, me = self.torch, self.dist, self.plan.rank
-        local_s = [t for r, t in sends if r == me]
-        local_r = [t for r, t in recvs if r == me]
-        for s, d in zip(local_s, local_r):
-            d.copy_(s)
-        ops = []
-        if dist is not None and self.plan.world > 1:
-            for r, t in recvs:
-                if r != me:
-                    ops.append(dist.P2POp(dist.irecv, t, r))
-            for r, t in sends:
-                if r != me:
-                    ops.append(dist.P2POp(dist.isend, t, r))
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
+    # -- persistent buffers and phase timers ----------------------------------------------------
+    def _buf(self, name, numel, like):
+        """A flat float32 buffer of at least `numel` elements, allocated once and reused every step."""
+        b = self._bufs.get(name)
+        if b is None or b.numel() < numel or b.device != like.device:
+            b = self.torch.empty(max(int(numel), 1), dtype=like.dtype, device=like.device)
+            self._bufs[name] = b
+        return b
 
-    def global_mean(self, vol):
-        """seq:420 for a sharded volume.  numpy reduces a float32 volume as pairwise sums of 8192-element
-        chunks accumulated left to right in float32; when every slab starts at a chunk boundary (Y*X a
-        multiple of 8192, as for 1024 x 1024 slices) the ranks form their chunks' sums, gather them and
-        accumulate in order: numpy's value exactly.  Otherwise: float64 sum per rank, one scalar
-        all-reduce (within 1 ulp)."""
-        torch, dist = self.torch, self.dist
-        Z, Y, X = self.plan.shape
-        if (Y * X) % 8192 == 0 and hasattr(self.backend, "chunk_sums"):
-            mine = np.ascontiguousarray(self.backend.chunk_sums(vol), dtype=np.float32)
-            if dist is not None and self.plan.world > 1:
-                per = [(e - s) * (Y * X // 8192) for s, e in self.plan.parts[0]]
-                buf = torch.zeros(max(per), dtype=torch.float32, device=vol.device)
-                buf[:mine.size] = torch.from_numpy(mine).to(vol.device)
-                got = [torch.empty_like(buf) for _ in range(self.plan.world)]
-                dist.all_gather(got, buf)
-                allsums = np.concatenate([g[:n].cpu().numpy() for g, n in zip(got, per)])
+    class _Phase:
+        def __init__(self, eng, name, cuda):
+            self.eng, self.name, self.cuda = eng, name, cuda and eng.timing
+
+        def __enter__(self):
+            if self.cuda:
+                self.a = self.eng.torch.cuda.Event(enable_timing=True)
+                self.a.record()
             else:
-                allsums = mine
-            tot = np.cumsum(allsums, dtype=np.float32)[-1]     # sequential float32 accumulation
-            return np.float32(tot / np.float32(Z * Y * X))
-        s = float(self.backend.local_sum(vol))
-        if dist is not None and self.plan.world > 1:
-            t = torch.tensor([s], dtype=torch.float64, device=vol.device)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            s = float(t.item())
-        Z, Y, X = self.plan.shape
-        return np.float32(s / (Z * Y * X))
+                self.t0 = time.perf_counter()
+            return self
 
-    def _fill_halos(self, stack, axis, r, mean, wrap):
-        """stack: (len + 2r, H, W) with its interior already in place."""
-        plan, me = self.plan, self.plan.rank
-        s, e = plan.parts[axis][me]
-        n_loc = e - s
-        if not wrap:
-            stack[:r].fill_(float(mean))
-            stack[r + n_loc:].fill_(float(mean))
-        interior = stack[r:r + n_loc]
-        sends, recvs = [], []
-        for src, dst, s_loc, d_pos, cnt in plan.halo_runs(axis, r, wrap):
-            if src == me:
-                sends.append((dst, interior[s_loc:s_loc + cnt] if dst != me else interior[s_loc:s_loc + cnt].clone()))
-            if dst == me:
-                recvs.append((src, stack[d_pos:d_pos + cnt]))
-        self._exchange(sends, recvs)
+        def __exit__(self, *exc):
+            if self.cuda:
+                b = self.eng.torch.cuda.Event(enable_timing=True)
+                b.record()
+                self.eng._pending.append((self.name, self.a, b))
+            elif self.eng.timing:
+                self.eng._ms[self.name] += (time.perf_counter() - self.t0) * 1e3
+            return False
 
-    def _repartition(self, slab, from_axis, to_axis, r):
-        """slab: (len_from, H, W) oriented for `from_axis`, holding this rank's part of the volume.
-        Returns the stack (len_to + 2r, H', W') oriented for `to_axis` with its interior filled."""
-        torch, plan, me = self.torch, self.plan, self.plan.rank
-        of, ot = self.ORIENT[from_axis], self.ORIENT[to_axis]
-        ts, te = plan.parts[to_axis][me]
-        dims_to = [plan.shape[a] for a in ot]
-        stack = torch.empty((te - ts + 2 * r, dims_to[1], dims_to[2]), dtype=slab.dtype, device=slab.device)
-        interior = stack[r:r + (te - ts)]
-        # view of my slab / my stack interior indexed by GLOBAL axes order (z, y, x)
-        slab_g = slab.permute(*[of.index(a) for a in (0, 1, 2)])
-        inter_g = interior.permute(*[ot.index(a) for a in (0, 1, 2)])
-        fs, fe = plan.parts[from_axis][me]
-        sends, recvs = [], []
-        for j in range(plan.world):
-            # block I send to j: my from-range x j's to-range
-            js, je = plan.parts[to_axis][j]
-            idx = [slice(None)] * 3
-            idx[to_axis] = slice(js, je)
-            sends.append((j, slab_g[tuple(idx)].contiguous()))
-            # block I receive from j: j's from-range x my to-range
-            gs, ge = plan.parts[from_axis][j]
-            shp = list(plan.shape)
-            shp[from_axis] = ge - gs
-            shp[to_axis] = te - ts
-            recvs.append((j, torch.empty(shp, dtype=slab.dtype, device=slab.device)))
-        self._exchange(sends, recvs)
-        for j, blk in recvs:
-            gs, ge = plan.parts[from_axis][j]
-            idx = [slice(None)] * 3
-            idx[from_axis] = slice(gs, ge)
-            inter_g[tuple(idx)].copy_(blk)
-        return stack
+    def _phase(self, name, like):
+        return self._Phase(self, name, like.is_cuda)
+
+    def phase_times(self):
+        """Milliseconds per phase on this rank since the last reset: the pass kernels ("compute"), packing blocks
+        into the receiver's orientation, the point-to-point exchange (waiting for the slowest peer included),
+        unpacking, and the global mean.  GPU phases are timed with events on the stream that runs them."""
+        if self._pending:
+            self.torch.cuda.synchronize()
+            for name, a, b in self._pending:
+                self._ms[name] += a.elapsed_time(b)
+            self._pending = []
+        return dict(self._ms)
+
+    def reset_phase_times(self):
+        self.phase_times()
+        self._ms = {p: 0.0 for p in self.PHASES}
+
+    # -- communication ----------------------------------------------------------------------------
+    def _host_staged(self, t):
+        """gloo moves host memory only: with it, device tensors are staged through the host (the CPU tests, and the
+        world-size-2 rehearsal of the HIP backend on a one-GPU box; RCCL needs one GPU per rank)."""
+        return t.is_cuda and self.dist is not None and self.dist.get_backend() == "gloo"
+
+    def _p2p(self, recvs, sends):
+        """recvs: [(tensor, src rank)], sends: [(tensor, dst rank)] -- one batched group, every pair at once."""
+        dist = self.dist
+        if not recvs and not sends:
+            return
+        if (recvs and self._host_staged(recvs[0][0])) or (sends and self._host_staged(sends[0][0])):
+            host_r = [(self.torch.empty(t.shape, dtype=t.dtype), t, r) for t, r in recvs]
+            ops = [dist.P2POp(dist.irecv, h, r) for h, _, r in host_r] + [dist.P2POp(dist.isend, t.cpu(), r) for t, r in sends]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            for h, t, _ in host_r:
+                t.copy_(h)
+            return
+        ops = [dist.P2POp(dist.irecv, t, r) for t, r in recvs] + [dist.P2POp(dist.isend, t, r) for t, r in sends]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    def _all_gather(self, t):
+        """[t of rank 0, t of rank 1, ...] (same shape on every rank)."""
+        if self._host_staged(t):
+            got = [self.torch.empty(t.shape, dtype=t.dtype) for _ in range(self.plan.world)]
+            self.dist.all_gather(got, t.cpu())
+            return got
+        got = [self.torch.empty_like(t) for _ in range(self.plan.world)]
+        self.dist.all_gather(got, t)
+        return got
+
+    def _schedule(self, A, B, r, wrap):
+        """Send and receive lists of this rank for the exchange A-partition -> pass along B (cached)."""
+        key = (A, B, r, wrap)
+        sc = self._sched.get(key)
+        if sc is None:
+            plan, me = self.plan, self.plan.rank
+            sends = [(j, plan.blocks(A, B, r, wrap, me, j)) for j in range(plan.world)]
+            recvs = [(i, plan.blocks(A, B, r, wrap, i, me)) for i in range(plan.world)]
+            sc = self._sched[key] = (sends, recvs)
+        return sc
+
+    @staticmethod
+    def _numel(rng):
+        n = 1
+        for lo, hi in rng.values():
+            n *= hi - lo
+        return n
+
+    def _exchange(self, slab, A, B, r, wrap, stack):
+        """Fill `stack` (oriented for B, K//2 = r halo slices either side) from the slabs of the A-partition."""
+        torch, dist, plan, me = self.torch, self.dist, self.plan, self.plan.rank
+        oa, ob = ORIENT[A], ORIENT[B]
+        sends, recvs = self._schedule(A, B, r, wrap)
+        n_send = sum(self._numel(rng) for _, bl in sends for _, rng in bl)
+        n_recv = sum(self._numel(rng) for i, bl in recvs if i != me for _, rng in bl)
+        sendbuf = self._buf("send", n_send, slab)
+        recvbuf = self._buf("recv", n_recv, slab)
+        sa = plan.parts[A][me][0]
+        # 1. pack every block into the receiver's orientation
+        soff, send_regions = 0, {}
+        with self._phase("pack", slab):
+            for j, bl in sends:
+                start = soff
+                for _, rng in bl:
+                    idx = tuple(slice(rng[ax][0] - (sa if ax == A else 0), rng[ax][1] - (sa if ax == A else 0)) for ax in oa)
+                    view = slab[idx].permute(*[oa.index(ax) for ax in ob])
+                    n = view.numel()
+                    self.backend.pack(view, sendbuf[soff:soff + n].view(view.shape))
+                    soff += n
+                send_regions[j] = (start, soff)
+        # 2. one batched group of point-to-point messages: every pair at once
+        roff, recv_regions = 0, {}
+        for i, bl in recvs:
+            if i == me:
+                continue
+            n = sum(self._numel(rng) for _, rng in bl)
+            recv_regions[i] = (roff, roff + n)
+            roff += n
+        with self._phase("exchange", slab):
+            if dist is not None and plan.world > 1:
+                self._p2p([(recvbuf[lo:hi], i) for i, (lo, hi) in recv_regions.items() if hi > lo],
+                          [(sendbuf[lo:hi], j) for j, (lo, hi) in send_regions.items() if j != me and hi > lo])
+        # 3. unpack: row-contiguous strided copies into the stack (the local block straight from the send buffer)
+        with self._phase("unpack", slab):
+            for i, bl in recvs:
+                buf, off = (sendbuf, send_regions[me][0]) if i == me else (recvbuf, recv_regions[i][0])
+                for p0, rng in bl:
+                    shp = [rng[ax][1] - rng[ax][0] for ax in ob]
+                    n = shp[0] * shp[1] * shp[2]
+                    dst = stack[p0:p0 + shp[0], rng[ob[1]][0]:rng[ob[1]][1], rng[ob[2]][0]:rng[ob[2]][1]]
+                    dst.copy_(buf[off:off + n].view(shp))
+                    off += n
+
+    def _fill_pad(self, stack, B, r, mean):
+        """Mean-padded pass: stack positions whose slice lies outside the volume (seq:88-89)."""
+        s, e = self.plan.parts[B][self.plan.rank]
+        n = self.plan.shape[B]
+        lo = max(0, r - s)                       # positions 0 .. lo-1 are before slice 0
+        hi = min(e - s + 2 * r, n - s + r)       # positions hi .. are after slice n-1
+        if lo > 0:
+            stack[:lo].fill_(float(mean))
+        if hi < e - s + 2 * r:
+            stack[hi:].fill_(float(mean))
+
+    # -- seq:420 for a sharded volume ----------------------------------------------------------------
+    def global_mean(self, vol):
+        """numpy's float32 vol.mean() of the WHOLE volume, bit for bit, from Z-slabs: numpy reduces a float32 array
+        as pairwise sums of 8192-element chunks accumulated left to right in float32.  Every chunk is summed (in
+        numpy's order, backend.chunk_sums) by the rank that holds its first element; a chunk that straddles a slab
+        boundary gets its missing elements from the following rank (at most 8191 of them).  The chunk sums are then
+        gathered and accumulated in order.  (The padded volume ends move by 1.2e-4 of the range per ulp of this
+        value, DESIGN.md 4.4 -- hence exactly numpy's value and not just a good mean.)"""
+        torch, dist, plan = self.torch, self.dist, self.plan
+        Z, Y, X = plan.shape
+        ntot = Z * Y * X
+        flat = vol.reshape(-1)
+        with self._phase("mean", vol):
+            if dist is None or plan.world == 1:
+                sums = np.asarray(self.backend.chunk_sums(flat), dtype=np.float32)
+                return np.float32(np.cumsum(sums, dtype=np.float32)[-1] / np.float32(ntot))
+            starts = [s * Y * X for s, _ in plan.parts[0]] + [ntot]
+            if min(starts[k + 1] - starts[k] for k in range(plan.world)) < 8192:
+                # tiny volume: a chunk may span several slabs; gather the whole thing (it is small)
+                m = max(starts[k + 1] - starts[k] for k in range(plan.world))
+                pad = torch.zeros(m, dtype=flat.dtype, device=flat.device)
+                pad[:flat.numel()] = flat
+                got = self._all_gather(pad)
+                whole = torch.cat([g[:starts[k + 1] - starts[k]] for k, g in enumerate(got)]).to(flat.device)
+                sums = np.asarray(self.backend.chunk_sums(whole), dtype=np.float32)
+                return np.float32(np.cumsum(sums, dtype=np.float32)[-1] / np.float32(ntot))
+            me = plan.rank
+            up = lambda v: -(-v // 8192) * 8192           # noqa: E731  next chunk boundary
+            first = [min(up(starts[k]), ntot) for k in range(plan.world)] + [ntot]   # first element of rank k's own chunks
+            head = first[me] - starts[me]                 # my leading elements belong to the previous rank's last chunk
+            tail = first[me + 1] - starts[me + 1]         # elements of my last chunk held by the next rank
+            tail_buf = torch.empty(tail, dtype=flat.dtype, device=flat.device) if tail > 0 else None
+            self._p2p([(tail_buf, me + 1)] if tail > 0 else [], [(flat[:head].contiguous(), me - 1)] if head > 0 else [])
+            own = flat[head:]
+            if tail > 0:
+                nfull = own.numel() // 8192 * 8192
+                parts = [np.asarray(self.backend.chunk_sums(own[:nfull]), dtype=np.float32)] if nfull else []
+                parts.append(np.asarray(self.backend.chunk_sums(torch.cat([own[nfull:], tail_buf])), dtype=np.float32))
+                mine = np.concatenate(parts)
+            else:
+                mine = np.asarray(self.backend.chunk_sums(own), dtype=np.float32) if own.numel() else np.zeros(0, np.float32)
+            per = [(first[k + 1] - first[k] + 8191) // 8192 for k in range(plan.world)]
+            assert mine.size == per[me], (mine.size, per)
+            buf = torch.zeros(max(max(per), 1), dtype=torch.float32, device=vol.device)
+            if mine.size:
+                buf[:mine.size] = torch.from_numpy(mine).to(vol.device)
+            got = self._all_gather(buf)
+            allsums = np.concatenate([g[:n].cpu().numpy() for g, n in zip(got, per)])
+            return np.float32(np.cumsum(allsums, dtype=np.float32)[-1] / np.float32(ntot))
 
     # -- the filter ------------------------------------------------------------------------
     def filter_3d(self, vol, kernels, params, mean=None):
-        """vol: this rank's Z-slab (zlen, Y, X).  Returns the filtered Z-slab (same partition).
-        kernels = [kz, ky, kx]; None skips an axis.  params: _lib.SweepParams."""
-        torch, plan = self.torch, self.plan
+        """vol: this rank's Z-slab (zlen, Y, X).  Returns the filtered Z-slab (same partition) -- a view of an
+        engine-owned buffer that the next call overwrites.  kernels = [kz, ky, kx]; None skips an axis."""
+        plan = self.plan
         if tuple(vol.shape) != (plan.zlen, plan.shape[1], plan.shape[2]):
             raise ValueError(f"rank {plan.rank} expects a {(plan.zlen,) + plan.shape[1:]} slab, got {tuple(vol.shape)}")
+        if not vol.is_contiguous():
+            vol = vol.contiguous()
         wrap = params.border_mode == 1
         if mean is None:
             mean = self.global_mean(vol) if not wrap else np.float32(0)
@@ -231,19 +399,23 @@ class SlabEngine:
                 continue
             k = np.ascontiguousarray(k, dtype=np.float64)
             r = k.size // 2
-            if cur_axis == axis:
-                n_loc = cur.shape[0]
-                stack = torch.empty((n_loc + 2 * r,) + tuple(cur.shape[1:]), dtype=cur.dtype, device=cur.device)
-                stack[r:r + n_loc].copy_(cur)
-            else:
-                stack = self._repartition(cur, cur_axis, axis, r)
-                n_loc = stack.shape[0] - 2 * r
-            self._fill_halos(stack, axis, r, mean, wrap)
-            out = torch.empty((n_loc,) + tuple(stack.shape[1:]), dtype=cur.dtype, device=cur.device)
-            self.backend.sweep_stack(stack, out, n_loc, stack.shape[1], stack.shape[2], k, params)
+            s, e = plan.parts[axis][plan.rank]
+            dims = [plan.shape[a] for a in ORIENT[axis]]
+            n_loc, H, W = e - s, dims[1], dims[2]
+            stack = self._buf(f"stack{axis}", (n_loc + 2 * r) * H * W, vol)[:(n_loc + 2 * r) * H * W].view(n_loc + 2 * r, H, W)
+            self._exchange(cur, cur_axis, axis, r, wrap, stack)
+            if not wrap:
+                self._fill_pad(stack, axis, r, mean)
+            out = self._buf(f"out{axis}", n_loc * H * W, vol)[:n_loc * H * W].view(n_loc, H, W)
+            with self._phase("compute", vol):
+                self.backend.sweep_stack(stack, out, n_loc, H, W, k, params)
             cur, cur_axis = out, axis
         if cur_axis != 0:
-            cur = self._repartition(cur, cur_axis, 0, 0)
+            res = self._buf("result", vol.numel(), vol)[:vol.numel()].view(vol.shape)
+            self._exchange(cur, cur_axis, 0, 0, False, res)
+            cur = res
         elif cur is vol:
-            cur = vol.clone()
+            res = self._buf("result", vol.numel(), vol)[:vol.numel()].view(vol.shape)
+            res.copy_(vol)
+            cur = res
         return cur

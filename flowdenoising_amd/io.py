@@ -124,7 +124,9 @@ def _page_dtype(tags, order):
     return np.dtype(f"{order}{kind}{bps // 8}")
 
 
-def read_tiff(path):
+def read_tiff(path, zrange=None, shape_only=False):
+    """zrange = (z0, z1): read only those pages (every rank of a multi-GPU run reads its own slab);
+    shape_only: return ((Z, Y, X), dtype) from the page directory without touching the pixel data."""
     with open(path, "rb") as f:
         bo = f.read(2)
         order = {b"II": "<", b"MM": ">"}.get(bo)
@@ -175,12 +177,20 @@ def read_tiff(path):
         desc = first.get(270, "") if isinstance(first.get(270, ""), str) else ""
         if len(pages) == 1 and desc.startswith("ImageJ=") and "images=" in desc:
             n = int(desc.split("images=")[1].split()[0])   # ImageJ hyperstack: one IFD, contiguous pages
-            f.seek(pages[0][0])
-            return np.fromfile(f, dtype=dt, count=n * H * W).reshape(n, H, W)
-        out = np.empty((len(pages), H, W), dtype=dt.newbyteorder("="))
-        for i, (src, h, w, d) in enumerate(pages):
+            if shape_only:
+                return (n, H, W), dt.newbyteorder("=")
+            z0, z1 = (0, n) if zrange is None else (max(0, zrange[0]), min(n, zrange[1]))
+            f.seek(pages[0][0] + z0 * H * W * dt.itemsize)
+            return np.fromfile(f, dtype=dt, count=(z1 - z0) * H * W).reshape(z1 - z0, H, W)
+        for (_, h, w, d) in pages:
             if (h, w, d) != (H, W, dt):
                 raise ValueError(f"{path}: pages differ in size or type")
+        if shape_only:
+            return (len(pages), H, W), dt.newbyteorder("=")
+        if zrange is not None:
+            pages = pages[max(0, zrange[0]):zrange[1]]
+        out = np.empty((len(pages), H, W), dtype=dt.newbyteorder("="))
+        for i, (src, h, w, d) in enumerate(pages):
             if isinstance(src, np.ndarray):
                 out[i] = src
             else:
@@ -262,6 +272,21 @@ def read_volume(path, mmap=False):
     if is_mrc_input(path):
         return read_mrc(path, mmap=mmap)
     return read_tiff(path)
+
+
+def volume_info(path):
+    """((Z, Y, X), dtype) of a volume file from its header / page directory only."""
+    if is_mrc_input(path):
+        v = read_mrc(path, mmap=True)
+        return tuple(v.shape), v.dtype.newbyteorder("=")
+    return read_tiff(path, shape_only=True)
+
+
+def read_slab(path, z0, z1):
+    """Slices [z0, z1) of a volume file, reading only their bytes (one rank's share of a multi-GPU run)."""
+    if is_mrc_input(path):
+        return np.array(read_mrc(path, mmap=True)[z0:z1])
+    return read_tiff(path, zrange=(z0, z1))
 
 
 def write_volume(path, vol, tiff_float32=False):

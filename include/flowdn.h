@@ -101,10 +101,32 @@ int fdn_farneback(fdn_handle h, const float* prev, const float* next, float* flo
                   int H, int W, int levels, int winsize, int iters, int poly_n,
                   double poly_sigma, int flags);
 
+/* The same with the images given as VIEWS, as the reference passes them: padded_vol[z + i] (seq:97),
+ * padded_vol[:, y + i, :] (seq:255: row stride Y*X), padded_vol[:, :, x + i] (seq:333: row stride Y*X, column
+ * stride X).  Pixel (r, c) of an image is base[r * row_stride + c * col_stride]; strides in ELEMENTS.  flow is
+ * contiguous.  The views are gathered by the library into its own pinned staging buffer: no copy on the caller's
+ * side (numpy hands over arr.ctypes.data and arr.strides). */
+int fdn_farneback_strided(fdn_handle h, const float* prev, ptrdiff_t prev_row_stride, ptrdiff_t prev_col_stride,
+                          const float* next, ptrdiff_t next_row_stride, ptrdiff_t next_col_stride,
+                          float* flow_inout, int H, int W, int levels, int winsize, int iters, int poly_n,
+                          double poly_sigma, int flags);
+/* ... and on DEVICE memory (views of a volume already in HBM; the flow stays on the device between the calls of
+ * a chain, seq:97-98): no host round trip, nothing synchronises. */
+int fdn_farneback_dev(fdn_handle h, const float* d_prev, ptrdiff_t prev_row_stride, ptrdiff_t prev_col_stride,
+                      const float* d_next, ptrdiff_t next_row_stride, ptrdiff_t next_col_stride,
+                      float* d_flow_inout, int H, int W, int levels, int winsize, int iters, int poly_n,
+                      double poly_sigma, int flags);
+
 /* ---- a-4  warp_slice(reference, flow)  (seq:51-57, par:55-63) --------------------- */
 /* dst(y,x) = cv2.remap(reference, float32(flow + grid), INTER_LINEAR, BORDER_REPLICATE):
  * 1/32-pixel quantised bilinear gather.  HOST pointers, contiguous. */
 int fdn_warp(fdn_handle h, const float* reference, const float* flow, float* dst, int H, int W);
+/* reference as a view (strides in elements, as above); flow and dst contiguous */
+int fdn_warp_strided(fdn_handle h, const float* reference, ptrdiff_t row_stride, ptrdiff_t col_stride,
+                     const float* flow, float* dst, int H, int W);
+/* DEVICE pointers; d_dst must not alias the reference */
+int fdn_warp_dev(fdn_handle h, const float* d_reference, ptrdiff_t row_stride, ptrdiff_t col_stride,
+                 const float* d_flow, float* d_dst, int H, int W);
 
 /* ---- a-5/6/7/10  OF_filter_along_{Z,Y,X} (seq:78-130, 235-288, 313-364),
  *      no_OF_filter_along_* (seq:171-192, 290-311, 396-417),

@@ -1,0 +1,50 @@
+"""Worker of tests/test_gpu_full.py::test_slab_engine_on_hip_backend_multi_rank (not a test module).
+One rank of a world-size-N SlabEngine run on the HIP backend.  With at least N GPUs every rank takes its own
+GPU and the exchange runs over RCCL ("nccl"); on a one-GPU box the ranks share GPU 0 and the exchange is staged
+through the host over gloo -- same engine code, same pack / unpack kernels, only the transport differs."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    vol_path, out_path, sig, border, levels, winsize = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    import torch
+    import torch.distributed as dist
+    from flowdenoising_amd import _lib
+    from flowdenoising_amd.distributed import SlabEngine, SlabPlan
+    ngpu = torch.cuda.device_count()
+    local = rank if ngpu >= world else 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if ngpu >= world:
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
+    vol = np.load(vol_path, mmap_mode="r")
+    plan = SlabPlan(vol.shape, world, rank)
+    slab = torch.from_numpy(np.ascontiguousarray(vol[plan.z0:plan.z0 + plan.zlen])).to(dev)
+    h = _lib.Handle(local)
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    kernels = [None if s == "-" else _lib.gaussian_kernel(float(s)) for s in sig.split(",")]
+    params = _lib.SweepParams(levels, winsize, 3, 5, 1.2, border, 1, 1)
+    eng = SlabEngine(plan, h, dist)
+    eng.filter_3d(slab, kernels, params)                      # a first step, so that the second reuses every buffer
+    out = eng.filter_3d(slab, kernels, params).cpu().numpy()
+    mean = eng.global_mean(slab)
+    np.save(f"{out_path}.{rank}.npy", out)
+    if rank == 0:
+        np.save(f"{out_path}.mean.npy", np.float32(mean))
+        print("backend", dist.get_backend(), "phases", {k: round(v, 2) for k, v in eng.phase_times().items()}, flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    h.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,6 +84,38 @@ def test_slab_engine_on_hip_backend_world1(fdn, oracle):
     assert rel_err(out, want) < TIGHT_TOL
 
 
+@pytest.mark.parametrize("world,shape,sig,border,l", [(2, (12, 70, 150), "1.0,0.5,1.0", 0, 0), (3, (13, 64, 128), "1.0,-,0.5", 1, 1)])
+def test_slab_engine_on_hip_backend_multi_rank(fdn, tmp_path, world, shape, sig, border, l):
+    """N > 1 on the HIP backend: `world` processes, each with its own fdn handle, run the slab engine (persistent
+    buffers, fdn_permute_dev packing, one exchange per pass, the chunk-sum mean) and must reproduce the single-GPU
+    OF_filter of the whole volume bit for bit.  On a node with >= `world` GPUs (the driver's scaling box) every rank
+    has its own GPU and the exchange is RCCL; on the one-GPU box the ranks share GPU 0 and the exchange is staged
+    through the host over gloo (tests/_dist_hip_worker.py)."""
+    import socket
+    from flowdenoising_amd import _lib
+    vol = _vol(shape, seed=33)
+    np.save(tmp_path / "v.npy", vol)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = {**os.environ, "RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_RANK": str(r), "MASTER_ADDR": "127.0.0.1",
+               "MASTER_PORT": str(port)}
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_hip_worker.py"), str(tmp_path / "v.npy"),
+                                       str(tmp_path / "o"), sig, str(border), str(l), "5"], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    print(outs[0][0].strip())
+    got = np.concatenate([np.load(f"{tmp_path}/o.{r}.npy") for r in range(world)])
+    ks = [None if s == "-" else fdn.get_gaussian_kernel(float(s)) for s in sig.split(",")]
+    want = fdn.OF_filter(vol, ks, l, 5, border_mode=border)
+    assert np.array_equal(got, want)
+    assert np.load(f"{tmp_path}/o.mean.npy") == vol.mean()
+
+
 def test_small_workspace_chunks_targets(fdn, oracle):
     from flowdenoising_amd.operators import handle
     vol = _vol((12, 34, 36), seed=9)
