@@ -30,7 +30,7 @@ class SweepParams(ctypes.Structure):
 # every symbol include/flowdn.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "fdn_create", "fdn_destroy", "fdn_last_error", "fdn_set_stream", "fdn_reset_stream", "fdn_synchronize",
-    "fdn_set_workspace_limit", "fdn_set_option", "fdn_malloc", "fdn_free", "fdn_memcpy_h2d", "fdn_memcpy_d2h",
+    "fdn_set_workspace_limit", "fdn_workspace_bytes", "fdn_set_option", "fdn_malloc", "fdn_free", "fdn_memcpy_h2d", "fdn_memcpy_d2h",
     "fdn_memset_f32", "fdn_gaussian_kernel", "fdn_farneback", "fdn_farneback_strided", "fdn_farneback_dev",
     "fdn_warp", "fdn_warp_strided", "fdn_warp_dev",
     "fdn_filter_axis_dev", "fdn_filter_axis", "fdn_filter_3d_dev", "fdn_filter_3d",
@@ -148,6 +148,12 @@ class Handle:
 
     def set_workspace_limit(self, nbytes):
         check(self._lib.fdn_set_workspace_limit(self._h, ctypes.c_size_t(int(nbytes))))
+
+    def workspace_bytes(self):
+        """Device memory the handle owns right now (fdn_workspace_bytes)."""
+        n = ctypes.c_size_t()
+        check(self._lib.fdn_workspace_bytes(self._h, ctypes.byref(n)))
+        return n.value
 
     def set_option(self, name, value):
         """fdn_set_option: "strict_order", "path", "fused_occ", "lds_pad" (see include/flowdn.h)."""

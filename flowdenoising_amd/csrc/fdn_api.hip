@@ -190,7 +190,9 @@ static void resolve_stamps(fdn_ctx* h)
 
 static int ensure(fdn_ctx* h, DevBuf& b, size_t bytes)
 {
-    if (b.cap >= bytes) return 0;
+    // under a workspace limit a buffer is also given back when it is more than a quarter too large, so that what
+    // an earlier, differently shaped call left behind does not count against the limit for ever
+    if (b.cap >= bytes && !(h->ws_limit && b.cap > bytes + bytes / 4 + 4096)) return 0;
     if (b.p) {
         FDN_HIP(hipStreamSynchronize(h->stream));
         FDN_HIP(hipFree(b.p));
@@ -222,6 +224,23 @@ static void gather_host(float* dst, const float* src, ptrdiff_t rs, ptrdiff_t cs
         if (cs == 1) memcpy(d, s, (size_t)W * sizeof(float));
         else for (int c = 0; c < W; c++) d[c] = s[(ptrdiff_t)c * cs];
     }
+}
+
+static size_t owned_bytes(const fdn_ctx* h)
+{
+    const DevBuf* bufs[] = {&h->R, &h->M0, &h->M1, &h->flow, &h->stack, &h->sweep_out, &h->vol_a, &h->vol_b, &h->partials, &h->pair,
+                            &h->vol_in, &h->vol_out, &h->Rpyr, &h->flow_pyr, &h->pyr_tmp, &h->area_tab};
+    size_t n = 0;
+    for (const DevBuf* b : bufs) n += b->cap;
+    return n;
+}
+
+static void free_all(fdn_ctx* h)
+{
+    DevBuf* bufs[] = {&h->R, &h->M0, &h->M1, &h->flow, &h->stack, &h->sweep_out, &h->vol_a, &h->vol_b, &h->partials, &h->pair,
+                      &h->vol_in, &h->vol_out, &h->Rpyr, &h->flow_pyr, &h->pyr_tmp, &h->area_tab};
+    for (DevBuf* b : bufs) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    h->area_key = {0, 0, 0, 0};
 }
 
 struct ScopedTimer {
@@ -351,7 +370,8 @@ static int build_R_pyramid(fdn_ctx* h, const float* imgs, int nimg, int H, int W
     size_t total = 0;
     for (size_t k = 1; k < lv.size(); k++) { lv[k].r_off = total; total += (size_t)nimg * 5 * lv[k].h * lv[k].w; }
     if (ensure(h, h->Rpyr, total * sizeof(float))) return -1;
-    const int chunk = std::max(1, std::min(nimg, (int)((size_t)(1u << 30) / (HW * 12))));
+    const size_t tmp_cap = h->ws_limit ? (size_t)1 << 28 : (size_t)1 << 30;
+    const int chunk = std::max(1, std::min(nimg, (int)(tmp_cap / (HW * 12))));
     if (ensure(h, h->pyr_tmp, (size_t)chunk * HW * 3 * sizeof(float))) return -1;
     float* tmp = (float*)h->pyr_tmp.p;
     float* blurred = tmp + (size_t)chunk * HW;
@@ -521,33 +541,37 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
     std::vector<PyrLevel> lv = pyramid_levels(p->levels, H, W);
     const bool pyramid = lv.size() > 1;
 
-    const int nstack = S + 2 * r;
-    if (ensure(h, h->R, (size_t)nstack * 5 * HW * sizeof(float))) return -1;
     PolyConsts pc;
     prepare_poly_consts(p->poly_n, p->poly_sigma, &pc);
-    {
-        ScopedTimer t(h, FDN_TIMER_POLYEXP);
-        launch_blur3_polyexp(stack, (float*)h->R.p, nstack, H, W, pc, st);
-    }
-    if (pyramid && build_R_pyramid(h, stack, nstack, H, W, lv, pc)) return -1;
     bool fused = fused_supported(p->winsize, p->iters, H, W) && h->tn.path == 0 && !h->tn.strict_order;
     for (size_t k = 1; k < lv.size(); k++) fused = fused && fused_supported(p->winsize, p->iters, lv[k].h, lv[k].w);
     // windows the 3-iteration kernel does not cover (winsize >= 10): one launch per iteration, matrices in LDS
     bool iter = !fused && p->iters >= 1 && h->tn.path != 1 && !h->tn.strict_order && iter_supported(p->winsize, H, W);
     for (size_t k = 1; k < lv.size(); k++) iter = iter && iter_supported(p->winsize, lv[k].h, lv[k].w);
     if (h->tn.path == 2 && !iter) return fail("path 2 (one-iteration kernels) cannot run winsize %d, iters %d here", p->winsize, p->iters);
-    // targets per batch, bounded by the workspace limit.  fused: two flow buffers (16 B/px), with a
-    // pyramid two more per coarser level;
-    // staged: flow 8 B + two M sets 40 B per pixel
-    size_t per_target = HW * (fused || iter ? (pyramid ? 22 : 16) : pyramid ? 52 : 48);
-    size_t budget = h->ws_limit;
-    if (!budget) {
+    // Scratch of a batch of C target slices, per pixel: the flows -- fused / iter: two buffers (16 B), with a pyramid two
+    // more per coarser level (22); staged: flow 8 B + two M sets 40 B (48, 52) -- and, when a workspace limit is set, the
+    // polynomial expansions too (20 B per slice, 26.7 with a pyramid): R is then rebuilt per batch for its C + 2r slices.
+    const size_t flow_px = fused || iter ? (pyramid ? 22 : 16) : pyramid ? 52 : 48;
+    const size_t r_px = pyramid ? 27 : 20;
+    const bool limited = h->ws_limit != 0;
+    int C;
+    if (limited) {
+        const size_t other = owned_bytes(h) - (h->R.cap + h->Rpyr.cap + h->pyr_tmp.cap + h->flow.cap + h->M0.cap + h->M1.cap + h->flow_pyr.cap);
+        const size_t fixed = (size_t)2 * r * HW * r_px + (pyramid ? std::min<size_t>((size_t)1 << 28, HW * 12 * (size_t)(S + 2 * r)) : 0);   // halo slices' R + blur scratch
+        const size_t per_target = HW * (flow_px + r_px);
+        if (h->ws_limit < other + fixed + per_target)
+            return fail("workspace limit of %zu bytes is too small: a pass over %d x %d images with K = %d needs at least %zu "
+                        "(%zu held by volumes and stacks)", h->ws_limit, W, H, K, other + fixed + per_target, other);
+        C = (int)std::min<size_t>((size_t)S, (h->ws_limit - other - fixed) / per_target);
+    } else {
         size_t fre = 0, tot = 0;
         FDN_HIP(hipMemGetInfo(&fre, &tot));
         size_t have = h->flow.cap + h->M0.cap + h->M1.cap;
-        budget = (fre + have) / 10 * 8;
+        C = (int)std::min<size_t>((size_t)S, std::max<size_t>(1, (fre + have) / 10 * 8 / (HW * flow_px)));
     }
-    int C = (int)std::min<size_t>((size_t)S, std::max<size_t>(1, budget / per_target));
+    const int CR = limited ? C : S;              // target slices per rebuild of R
+    if (ensure(h, h->R, (size_t)(CR + 2 * r) * 5 * HW * sizeof(float))) return -1;
     float* R = (float*)h->R.p;
     if (fused || iter) {
         if (ensure(h, h->flow, (size_t)C * HW * 16)) return -1;
@@ -559,11 +583,22 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
         if (pyramid && ensure_flow_pyramid(h, lv, C)) return -1;
     }
     float* flow = (float*)h->flow.p;
-    float* flowB = flow + (size_t)C * HW * 2; // fused only
+    float* flowB = flow + (size_t)C * HW * 2; // fused / iter only
     float* M0 = (float*)h->M0.p; float* M1 = (float*)h->M1.p;
+    const float* const stack_all = stack;
+    float* const out_all = out;
 
-    for (int c0 = 0; c0 < S; c0 += C) {
-        int n = std::min(C, S - c0);
+    for (int cr0 = 0; cr0 < S; cr0 += CR) {
+    const int nr = std::min(CR, S - cr0);
+    stack = stack_all + (size_t)cr0 * HW;        // the batch's own stack: target q is its slice q + r
+    out = out_all + (size_t)cr0 * HW;
+    {
+        ScopedTimer t(h, FDN_TIMER_POLYEXP);
+        launch_blur3_polyexp(stack, R, nr + 2 * r, H, W, pc, st);
+    }
+    if (pyramid && build_R_pyramid(h, stack, nr + 2 * r, H, W, lv, pc)) return -1;
+    for (int c0 = 0; c0 < nr; c0 += C) {
+        int n = std::min(C, nr - c0);
         float* acc = out + (size_t)c0 * HW;
         launch_fill(acc, 0.f, (size_t)n * HW, st);
         for (int side = 0; side < 2; side++) {
@@ -615,6 +650,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
             }
         }
     }
+    }   // batches of R
     FDN_HIP(hipGetLastError());
     return 0;
 }
@@ -626,6 +662,17 @@ static void axis_dims(int Z, int Y, int X, int axis, int* S, int* H, int* W)
     if (axis == 0) { *S = Z; *H = Y; *W = X; }
     else if (axis == 1) { *S = Y; *H = Z; *W = X; }
     else { *S = X; *H = Z; *W = Y; }
+}
+
+// slices [g0, g0 + cnt) of `d_in` along `axis` (all inside the volume) -> cnt consecutive images at dst
+static int load_slices(fdn_ctx* h, const float* d_in, float* dst, int g0, int cnt, int Z, int Y, int X, int axis)
+{
+    if (cnt <= 0) return 0;
+    hipStream_t st = h->stream;
+    if (axis == 0) FDN_HIP(hipMemcpyAsync(dst, d_in + (size_t)g0 * Y * X, (size_t)cnt * Y * X * sizeof(float), hipMemcpyDeviceToDevice, st));
+    else if (axis == 1) launch_permute(d_in + (size_t)g0 * X, dst, cnt, Z, X, X, (int64_t)Y * X, 1, st);          // dst[y][z][x]
+    else launch_permute(d_in + g0, dst, cnt, Z, Y, 1, (int64_t)Y * X, X, st);                                      // dst[x][z][y]
+    return 0;
 }
 
 static int filter_axis_dev(fdn_ctx* h, const float* d_in, float* d_out, int Z, int Y, int X, int axis,
@@ -640,35 +687,53 @@ static int filter_axis_dev(fdn_ctx* h, const float* d_in, float* d_out, int Z, i
     const int r = K / 2;
     const size_t HW = (size_t)H * W;
     hipStream_t st = h->stream;
-    if (ensure(h, h->stack, (size_t)(S + 2 * r) * HW * sizeof(float))) return -1;
+    // Targets per chunk of the pass.  Without a workspace limit: the whole pass at once.  With one: what fits next to
+    // the buffers that must stay (intermediate volumes, staging) -- per target slice the stack (4 B/px), the re-oriented
+    // output (4, Y and X passes) and the sweep's own expansions and flows; the K-1 halo slices come on top per chunk.
+    int NP = S;
+    if (h->ws_limit) {
+        const size_t keep = h->vol_a.cap + h->vol_b.cap + h->vol_in.cap + h->vol_out.cap + h->pair.cap + h->partials.cap + h->area_tab.cap;
+        const bool pyr = p->use_of && pyramid_levels(p->levels, H, W).size() > 1;
+        const size_t sweep_px = !p->use_of ? 0 : (pyr ? 27 : 20) + 52;        // the slower path's flows: an upper bound
+        const size_t per_target = HW * (4 + (axis ? 4 : 0) + sweep_px);
+        const size_t fixed = (size_t)2 * r * HW * (4 + (p->use_of ? (pyr ? 27 : 20) : 0)) + (pyr ? std::min<size_t>((size_t)1 << 28, HW * 12 * (size_t)(S + 2 * r)) : 0);
+        if (h->ws_limit < keep + fixed + per_target)
+            return fail("workspace limit of %zu bytes is too small for a pass over %d x %d images with K = %d: needs at least %zu",
+                        h->ws_limit, W, H, K, keep + fixed + per_target);
+        NP = (int)std::min<size_t>((size_t)S, (h->ws_limit - keep - fixed) / per_target);
+    }
+    if (ensure(h, h->stack, (size_t)(NP + 2 * r) * HW * sizeof(float))) return -1;
     float* stack = (float*)h->stack.p;
-    float* interior = stack + (size_t)r * HW;
-    {
-        ScopedTimer t(h, FDN_TIMER_PERMUTE);
-        if (axis == 0) FDN_HIP(hipMemcpyAsync(interior, d_in, (size_t)S * HW * sizeof(float), hipMemcpyDeviceToDevice, st));
-        else if (axis == 1) launch_permute(d_in, interior, Y, Z, X, X, (int64_t)Y * X, 1, st);
-        else launch_permute(d_in, interior, X, Z, Y, 1, (int64_t)Y * X, X, st);
-        if (p->border_mode == FDN_BORDER_WRAP) {
-            for (int q = 0; q < r; q++) { // par:312: (s + i - ks2) % n
-                int lo = ((q - r) % S + S) % S, hi = (S + q) % S;
-                FDN_HIP(hipMemcpyAsync(stack + (size_t)q * HW, interior + (size_t)lo * HW, HW * sizeof(float), hipMemcpyDeviceToDevice, st));
-                FDN_HIP(hipMemcpyAsync(stack + (size_t)(r + S + q) * HW, interior + (size_t)hi * HW, HW * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (axis != 0 && ensure(h, h->sweep_out, (size_t)NP * HW * sizeof(float))) return -1;
+    for (int s0 = 0; s0 < S; s0 += NP) {
+        const int np = std::min(NP, S - s0);
+        {   // stack position q holds slice s0 - r + q: from the volume, wrapped (par:312), or the pad value (seq:88-89)
+            ScopedTimer t(h, FDN_TIMER_PERMUTE);
+            const int nq = np + 2 * r;
+            int q = 0;
+            while (q < nq) {
+                int g = s0 - r + q;
+                if (p->border_mode == FDN_BORDER_WRAP) g = ((g % S) + S) % S;
+                if (g < 0 || g >= S) {                       // a run of padding
+                    int cnt = g < 0 ? std::min(-g, nq - q) : nq - q;
+                    launch_fill(stack + (size_t)q * HW, pad_value, (size_t)cnt * HW, st);
+                    q += cnt;
+                } else {                                     // a run of consecutive slices inside the volume
+                    int cnt = std::min(S - g, nq - q);
+                    if (load_slices(h, d_in, stack + (size_t)q * HW, g, cnt, Z, Y, X, axis)) return -1;
+                    q += cnt;
+                }
             }
-        } else { // seq:88-89
-            launch_fill(stack, pad_value, (size_t)r * HW, st);
-            launch_fill(stack + (size_t)(r + S) * HW, pad_value, (size_t)r * HW, st);
         }
-    }
-    float* sw_out = d_out;
-    if (axis != 0) {
-        if (ensure(h, h->sweep_out, (size_t)S * HW * sizeof(float))) return -1;
-        sw_out = (float*)h->sweep_out.p;
-    }
-    if (sweep_stack(h, stack, sw_out, S, H, W, kernel, K, p)) return -1;
-    if (axis != 0) {
-        ScopedTimer t(h, FDN_TIMER_PERMUTE);
-        if (axis == 1) launch_permute(sw_out, d_out, Z, Y, X, X, (int64_t)Z * X, 1, st);      // out[z][y][x] = t[y][z][x]
-        else launch_permute(sw_out, d_out, Z, Y, X, Y, 1, (int64_t)Z * Y, st);                // out[z][y][x] = t[x][z][y]
+        float* sw_out = axis == 0 ? d_out + (size_t)s0 * HW : (float*)h->sweep_out.p;
+        if (sweep_stack(h, stack, sw_out, np, H, W, kernel, K, p)) return -1;
+        if (axis != 0) {
+            ScopedTimer t(h, FDN_TIMER_PERMUTE);
+            if (axis == 1)      // out[z][s0 + yy][x] = t[yy][z][x]
+                launch_permute(sw_out, d_out + (size_t)s0 * X, Z, np, X, X, (int64_t)Z * X, 1, st, (int64_t)Y * X, X);
+            else                // out[z][y][s0 + xx] = t[xx][z][y]
+                launch_permute(sw_out, d_out + s0, Z, Y, np, Y, 1, (int64_t)Z * Y, st, (int64_t)Y * X, X);
+        }
     }
     FDN_HIP(hipGetLastError());
     return 0;
@@ -767,9 +832,7 @@ FDN_API int fdn_destroy(fdn_handle h)
     if (!h) return 0;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf* bufs[] = {&h->R, &h->M0, &h->M1, &h->flow, &h->stack, &h->sweep_out, &h->vol_a, &h->vol_b, &h->partials, &h->pair,
-                      &h->vol_in, &h->vol_out, &h->Rpyr, &h->flow_pyr, &h->pyr_tmp, &h->area_tab};
-    for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+    free_all(h);
     if (h->pinned) (void)hipHostFree(h->pinned);
     resolve_stamps(h);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -805,7 +868,16 @@ FDN_API int fdn_synchronize(fdn_handle h)
 FDN_API int fdn_set_workspace_limit(fdn_handle h, size_t bytes)
 {
     FDN_ENTER(h);
+    FDN_HIP(hipStreamSynchronize(h->stream));
+    free_all(h);              // buffers only ever grow: start over so that the new limit holds from the next call on
     h->ws_limit = bytes;
+    return 0;
+}
+FDN_API int fdn_workspace_bytes(fdn_handle h, size_t* bytes_out)
+{
+    FDN_ENTER(h);
+    if (!bytes_out) return fail("bytes_out is NULL");
+    *bytes_out = owned_bytes(h);
     return 0;
 }
 FDN_API int fdn_set_option(fdn_handle h, const char* name, long value)

@@ -100,8 +100,9 @@ struct FlowSource { int h, w; double sx, sy; };   // h == 0: flow_in has the ima
 void launch_fill(float* dst, float value, size_t count, hipStream_t st);
 // out[r][c] (contiguous H x W) = in[r * rs + c * cs]  (strides in elements; a slice view of a volume)
 void launch_copy_strided(const float* in, int64_t rs, int64_t cs, float* out, int H, int W, hipStream_t st);
+// out[a][b][c] = in[a*sa + b*sb + c*sc]; out element (a, b, c) at out + a*oa + b*ob + c (oa = ob = 0: contiguous)
 void launch_permute(const float* in, float* out, int A, int B, int C, int64_t sa, int64_t sb,
-                    int64_t sc, hipStream_t st);
+                    int64_t sc, hipStream_t st, int64_t oa = 0, int64_t ob = 0);
 // partial sums (f64) into `partials` (nblocks entries); returns nblocks used
 // sums[c] = numpy's float32 pairwise sum of in[8192 c .. 8192 c + 8191]
 void launch_np_chunk_sums(const float* in, size_t nchunks, float* sums, hipStream_t st);

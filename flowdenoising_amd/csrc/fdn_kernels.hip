@@ -535,19 +535,22 @@ void launch_copy_strided(const float* in, int64_t rs, int64_t cs, float* out, in
 // sc == 1: row copies.  Otherwise a 32x32 LDS-tiled transpose over the out dims
 // (u, C) where u is the out dim whose in-stride is 1, so both sides stay coalesced.
 // ---------------------------------------------------------------------------------
+// out[a][b][c] lives at out + a*oa + b*ob + c: rows of C contiguous elements; (oa, ob) = (B*C, C) for a contiguous
+// result, anything else to drop a block into a larger array (a chunk of a pass back into the volume).
 __global__ __launch_bounds__(256) void k_permute_rows(const float* __restrict__ in, float* __restrict__ out,
-                                                      int A, int B, int C, int64_t sa, int64_t sb)
+                                                      int A, int B, int C, int64_t sa, int64_t sb, int64_t oa, int64_t ob)
 {
     int64_t ab = blockIdx.x;
     int a = (int)(ab / B), b = (int)(ab - (int64_t)a * B);
     const float* src = in + a * sa + b * sb;
-    float* dst = out + ab * C;
+    float* dst = out + a * oa + b * ob;
     for (int c = threadIdx.x; c < C; c += 256) dst[c] = src[c];
 }
 // MODE 0: in-stride-1 dim is B (tile over b,c; grid.z = a).  MODE 1: it is A (tile over a,c; grid.z = b).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_permute_tiled(const float* __restrict__ in, float* __restrict__ out,
-                                                       int A, int B, int C, int64_t sa, int64_t sb, int64_t sc)
+                                                       int A, int B, int C, int64_t sa, int64_t sb, int64_t sc,
+                                                       int64_t oa, int64_t ob)
 {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
@@ -567,19 +570,21 @@ __global__ __launch_bounds__(256) void k_permute_tiled(const float* __restrict__
         int u = u0 + ty + r, c = c0 + tx;
         if (u < U && c < C) {
             int a = MODE == 0 ? other : u, b = MODE == 0 ? u : other;
-            out[((int64_t)a * B + b) * C + c] = tile[tx][ty + r];
+            out[(int64_t)a * oa + (int64_t)b * ob + c] = tile[tx][ty + r];
         }
     }
 }
-void launch_permute(const float* in, float* out, int A, int B, int C, int64_t sa, int64_t sb, int64_t sc, hipStream_t st)
+void launch_permute(const float* in, float* out, int A, int B, int C, int64_t sa, int64_t sb, int64_t sc, hipStream_t st,
+                    int64_t oa, int64_t ob)
 {
     if (A <= 0 || B <= 0 || C <= 0) return;
+    if (oa == 0 && ob == 0) { oa = (int64_t)B * C; ob = C; }
     if (sc == 1) {
-        hipLaunchKernelGGL(k_permute_rows, dim3((unsigned)((int64_t)A * B)), dim3(256), 0, st, in, out, A, B, C, sa, sb);
+        hipLaunchKernelGGL(k_permute_rows, dim3((unsigned)((int64_t)A * B)), dim3(256), 0, st, in, out, A, B, C, sa, sb, oa, ob);
     } else if (sb == 1) {
-        hipLaunchKernelGGL(k_permute_tiled<0>, dim3((B + 31) / 32, (C + 31) / 32, A), dim3(256), 0, st, in, out, A, B, C, sa, sb, sc);
+        hipLaunchKernelGGL(k_permute_tiled<0>, dim3((B + 31) / 32, (C + 31) / 32, A), dim3(256), 0, st, in, out, A, B, C, sa, sb, sc, oa, ob);
     } else { // sa == 1 (validated by the caller)
-        hipLaunchKernelGGL(k_permute_tiled<1>, dim3((A + 31) / 32, (C + 31) / 32, B), dim3(256), 0, st, in, out, A, B, C, sa, sb, sc);
+        hipLaunchKernelGGL(k_permute_tiled<1>, dim3((A + 31) / 32, (C + 31) / 32, B), dim3(256), 0, st, in, out, A, B, C, sa, sb, sc, oa, ob);
     }
 }
 

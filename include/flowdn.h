@@ -65,9 +65,13 @@ const char* fdn_last_error(void);
 int fdn_set_stream(fdn_handle h, void* hip_stream);
 int fdn_reset_stream(fdn_handle h);
 int fdn_synchronize(fdn_handle h);
-/* Cap on library-owned scratch (polynomial expansions, flows); 0 = default (device free
- * memory minus a reserve).  Sweeps are chunked over target slices to respect it. */
+/* Cap on ALL device memory the handle owns (stacks, re-oriented pass outputs, intermediate volumes, polynomial
+ * expansions, flows, matrices); 0 = no cap (whole passes at once, flows bounded by the free device memory).
+ * With a cap every pass is cut into chunks of target slices (each with its K/2 halo slices either side) that fit;
+ * results do not depend on it, bit for bit.  Too small a cap for one target slice is an error, not a fallback.
+ * Setting it releases what the handle holds.  fdn_workspace_bytes reports what it holds now. */
 int fdn_set_workspace_limit(fdn_handle h, size_t bytes);
+int fdn_workspace_bytes(fdn_handle h, size_t* bytes_out);
 
 /* Switches of a live handle (tests and experiments; fdn_create reads the same from the environment:
  * FDN_STRICT_ORDER, FDN_PATH / FDN_FORCE_STAGED, FDN_FUSED_OCC, FDN_LDS_PAD).  Every path gives the same

@@ -116,17 +116,57 @@ def test_slab_engine_on_hip_backend_multi_rank(fdn, tmp_path, world, shape, sig,
     assert np.load(f"{tmp_path}/o.mean.npy") == vol.mean()
 
 
-def test_small_workspace_chunks_targets(fdn, oracle):
+@pytest.mark.parametrize("l,w", [(0, 5), (1, 5), (0, 15)])
+def test_workspace_limit_bounds_every_buffer(fdn, oracle, l, w):
+    """fdn_set_workspace_limit caps everything the handle owns (stack, re-oriented pass output, intermediate volumes,
+    expansions, flows): passes are cut into chunks of target slices, results do not change by a bit, and a cap too
+    small for one target slice is an error."""
+    from flowdenoising_amd._lib import FlowdnError
     from flowdenoising_amd.operators import handle
-    vol = _vol((12, 34, 36), seed=9)
-    k = fdn.get_gaussian_kernel(1.0)
+    vol = _vol((14, 40, 70), seed=9)
+    ks = [fdn.get_gaussian_kernel(1.0), fdn.get_gaussian_kernel(0.5), fdn.get_gaussian_kernel(1.0)]
+    want = fdn.OF_filter(vol, ks, l, w)
     h = handle()
-    h.set_workspace_limit(3 * 34 * 36 * 16)   # room for 3 targets' flows per batch
+    limit = 8 * vol.nbytes + (6 << 20 if l else 0)        # two intermediate volumes + chunks of a few target slices
+    h.set_workspace_limit(limit)
     try:
-        got = fdn.OF_filter_along_Z(vol, k, 0, 5, vol.mean())
+        assert h.workspace_bytes() == 0
+        got = fdn.OF_filter(vol, ks, l, w)
+        assert h.workspace_bytes() <= limit
+        h.set_workspace_limit(vol.nbytes // 4)
+        with pytest.raises(FlowdnError, match="too small"):
+            fdn.OF_filter(vol, ks, l, w)
     finally:
         h.set_workspace_limit(0)
-    assert rel_err(got, oracle.filter_along_axis(vol, 0, k, 0, 5, vol.mean())) < TIGHT_TOL
+    assert np.array_equal(got, want)
+    assert rel_err(got, oracle.OF_filter(vol, ks, l, w, nthreads=8)) < TIGHT_TOL
+
+
+def test_config2_under_a_16_gib_workspace_limit(fdn):
+    """configs[2] (2 GiB volume, 26 GiB of scratch when unlimited) completes bit-equal when the handle may own 16 GiB."""
+    import torch
+    from flowdenoising_amd import _lib, synth
+    shape = (512, 1024, 1024)
+    vol = synth.make_volume(shape, seed=1234 + 3, amplitude=100.0, xp=torch, device=torch.device("cuda", 0))
+    k = _lib.gaussian_kernel(2.0)
+    params = _lib.SweepParams(0, 5, 3, 5, 1.2, _lib.BORDER_MEAN_PAD, 1, 1)
+    h = _lib.Handle(0)
+    try:
+        h.set_stream(torch.cuda.current_stream().cuda_stream)
+        mean = h.mean_dev(vol.data_ptr(), vol.numel())
+        a, b = torch.empty_like(vol), torch.empty_like(vol)
+        h.filter_3d_dev(vol.data_ptr(), a.data_ptr(), shape, [k, k, k], mean, params)
+        torch.cuda.synchronize()
+        unlimited = h.workspace_bytes()
+        h.set_workspace_limit(16 << 30)
+        h.filter_3d_dev(vol.data_ptr(), b.data_ptr(), shape, [k, k, k], mean, params)
+        torch.cuda.synchronize()
+        assert h.workspace_bytes() <= (16 << 30) < unlimited
+        assert torch.equal(a, b)
+    finally:
+        h.close()
+        del vol
+        torch.cuda.empty_cache()
 
 
 def test_wide_window_small_image(fdn, oracle):

@@ -127,6 +127,36 @@ def test_of_filter_pyramid_on_the_fused_kernel(fdn, oracle, shape, l):
     assert rel_err(got, want) < TIGHT_TOL
 
 
+def test_pair_entry_points_take_views_and_device_pointers(fdn, oracle):
+    """The reference hands cv2 VIEWS of the padded volume: padded_vol[:, y + i, :] (seq:255) and
+    padded_vol[:, :, x + i] (seq:333).  fdn_farneback_strided / fdn_warp_strided take them as they are
+    (pointer + element strides, gathered into the handle's pinned staging); fdn_farneback_dev / fdn_warp_dev do
+    the same on a volume that already lives in HBM, flow included, without any host round trip."""
+    torch = pytest.importorskip("torch")
+    from flowdenoising_amd.operators import handle
+    vol = _vol((40, 44, 52), seed=77)
+    h = handle()
+    d_vol = torch.from_numpy(vol).cuda()
+    for name, tgt, ref, dt, dr in [
+            ("Y", vol[:, 20, :], vol[:, 21, :], d_vol[:, 20, :], d_vol[:, 21, :]),      # row stride Y*X, column stride 1
+            ("X", vol[:, :, 30], vol[:, :, 31], d_vol[:, :, 30], d_vol[:, :, 31])]:    # row stride Y*X, column stride X
+        assert not tgt.flags["C_CONTIGUOUS"]
+        H, W = tgt.shape
+        f0 = (np.random.default_rng(5).standard_normal((H, W, 2)) * 0.3).astype(np.float32)
+        want = oracle.get_flow(np.ascontiguousarray(ref), np.ascontiguousarray(tgt), 0, 5, f0.copy())
+        got = fdn.get_flow(ref, tgt, 0, 5, f0.copy())                                   # views in, no copy on this side
+        assert np.array_equal(got, want), name
+        assert np.array_equal(fdn.warp_slice(ref, got), oracle.warp_slice(np.ascontiguousarray(ref), want)), name
+        d_flow = torch.from_numpy(f0).cuda()
+        torch.cuda.synchronize()
+        h.farneback_dev(dt.data_ptr(), dt.stride(), dr.data_ptr(), dr.stride(), d_flow.data_ptr(), H, W, 0, 5, 3, 5, 1.2, 4)
+        d_out = torch.empty((H, W), dtype=torch.float32, device="cuda")
+        h.warp_dev(dr.data_ptr(), dr.stride(), d_flow.data_ptr(), d_out.data_ptr(), H, W)
+        h.synchronize()
+        assert np.array_equal(d_flow.cpu().numpy(), want), name
+        assert np.array_equal(d_out.cpu().numpy(), oracle.warp_slice(np.ascontiguousarray(ref), want)), name
+
+
 def test_get_flow_updates_prev_flow_in_place(fdn):
     rng = np.random.default_rng(4)
     a, b = _img(rng, 40, 40), _img(rng, 40, 40)
