@@ -146,7 +146,7 @@ def sweep_line(h, vol, shape, kernel, params, mean):
     from flowdenoising_amd import _lib
     import torch
     Z, Y, X = shape
-    n = min(64, Z)
+    n = min(256, Z)
     out = torch.empty((n, Y, X), dtype=torch.float32, device=vol.device)
     h.set_option("path", 1)
     try:

@@ -138,6 +138,14 @@ static void cv_gaussian_kernel_f32(int n, double sigma, float* k)
  * Symmetric small-kernel forms for n==3 / n==5 (SymmRowSmallFilter), left-to-right
  * tap accumulation otherwise (RowFilter); vertical pass is SymmColumnFilter:
  * s = k[c]*S[c] ; s += k[c+j]*(S[c+j] + S[c-j]). */
+/* Sensitivity switch (tools/fma_sensitivity.py), NOT a claim about any particular cv2 build: stock x86 wheels run
+ * these filters through SIMD code whose v_muladd becomes a fused multiply-add on AVX2/FMA3 machines (and plain C on
+ * the row tails); with fdo_set_fma(1) every tap of the blur and the vertical resize pass is fused, to measure how far
+ * that can move a result.  At levels = 0 the taps are powers of two and fusing changes nothing. */
+static int g_fma = 0;
+FDO_EXPORT void fdo_set_fma(int on) { g_fma = on; }
+static inline float mad(float a, float b, float c) { return g_fma ? fmaf(a, b, c) : a * b + c; }
+
 static void cv_gaussian_blur_f32(const float* src, float* dst, int H, int W, int n, double sigma)
 {
     float* k = (float*)malloc(n * sizeof(float));
@@ -150,13 +158,13 @@ static void cv_gaussian_blur_f32(const float* src, float* dst, int H, int W, int
         for (int x = 0; x < W; x++) {
             float s0;
             if (n == 3) {
-                s0 = S[x] * k[1] + (S[reflect101(x - 1, W)] + S[reflect101(x + 1, W)]) * k[2];
+                s0 = mad(S[reflect101(x - 1, W)] + S[reflect101(x + 1, W)], k[2], S[x] * k[1]);
             } else if (n == 5) {
-                s0 = S[x] * k[2] + (S[reflect101(x - 1, W)] + S[reflect101(x + 1, W)]) * k[3]
-                     + (S[reflect101(x - 2, W)] + S[reflect101(x + 2, W)]) * k[4];
+                s0 = mad(S[reflect101(x - 1, W)] + S[reflect101(x + 1, W)], k[3], S[x] * k[2]);
+                s0 = mad(S[reflect101(x - 2, W)] + S[reflect101(x + 2, W)], k[4], s0);
             } else {
                 s0 = k[0] * S[reflect101(x - c, W)];
-                for (int j = 1; j < n; j++) s0 += k[j] * S[reflect101(x - c + j, W)];
+                for (int j = 1; j < n; j++) s0 = mad(k[j], S[reflect101(x - c + j, W)], s0);
             }
             T[x] = s0;
         }
@@ -169,7 +177,7 @@ static void cv_gaussian_blur_f32(const float* src, float* dst, int H, int W, int
             const float* Sp = tmp + (size_t)reflect101(y + j, H) * W;
             const float* Sm = tmp + (size_t)reflect101(y - j, H) * W;
             float kj = k[c + j];
-            for (int x = 0; x < W; x++) D[x] += kj * (Sp[x] + Sm[x]);
+            for (int x = 0; x < W; x++) D[x] = mad(kj, Sp[x] + Sm[x], D[x]);
         }
     }
     free(tmp);
@@ -213,7 +221,7 @@ static void cv_resize_linear_f32(const float* src, int sh, int sw, float* dst, i
         }
         float b1 = fy, b0 = 1.f - fy;
         float* D = dst + (size_t)dy * dw * cn;
-        for (int i = 0; i < dw * cn; i++) D[i] = r0[i] * b0 + r1[i] * b1;
+        for (int i = 0; i < dw * cn; i++) D[i] = mad(r0[i], b0, r1[i] * b1);
     }
     free(r0); free(r1); free(xofs); free(xa);
 }

@@ -59,6 +59,11 @@ def lib():
     return _lib
 
 
+def set_fma(on):
+    """Sensitivity switch: fuse every multiply-add of the pyramid blur and of the vertical resize pass (see fdn_oracle.c)."""
+    lib().fdo_set_fma(ctypes.c_int(int(bool(on))))
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
