@@ -141,12 +141,13 @@ def committed_profile(kernel, run_cfg):
 
 def sweep_line(h, vol, shape, kernel, params, mean):
     """north_star states its 50 % target on the warped-Gaussian sweep.  In the product that sweep is fused into the
-    Farneback kernel (its 12 B/px are inside `roofline`); as a kernel of its own it exists on the staged path
-    (k_warp_accumulate): time it there, on a Z pass over the first 64 slices."""
-    from flowdenoising_amd import _lib
+    Farneback kernel (its 12 B/px are inside `roofline`); as a kernel of its own it exists on the per-stage path
+    (k_sweep_side: one launch folds the K//2 warped neighbours of one side into the accumulator, which stays in a
+    register): time it there, on a Z pass over the first 256 slices."""
     import torch
     Z, Y, X = shape
     n = min(256, Z)
+    r = kernel.size // 2
     out = torch.empty((n, Y, X), dtype=torch.float32, device=vol.device)
     h.set_option("path", 1)
     try:
@@ -161,14 +162,13 @@ def sweep_line(h, vol, shape, kernel, params, mean):
         return None
     px = n * Y * X
     avg_s = ms / cnt * 1e-3
-    model, real = 12.0, 20.0
-    return {"kernel": "k_warp_accumulate", "bound": "hbm", "bytes_per_px_model": model,
-            "achieved": round(model * px / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(model * px / avg_s / 1e9 / HBM_PEAK_GBS, 4),
-            "moved_GBps": round(real * px / avg_s / 1e9, 1), "moved_frac": round(real * px / avg_s / 1e9 / HBM_PEAK_GBS, 4),
+    bpp = 12.0 * r + 8.0            # flow 8 + neighbour 4 per pair; accumulator read + written once per side
+    return {"kernel": "k_sweep_side", "bound": "hbm", "bytes_per_px": bpp,
+            "achieved": round(bpp * px / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(bpp * px / avg_s / 1e9 / HBM_PEAK_GBS, 4),
             "avg_launch_ms": round(ms / cnt, 4), "launches": cnt,
-            "note": "SURVEY 8(d) prices the sweep at flow 8 + neighbour 4 B per pixel and pair; as a separate kernel it "
-                    f"also reads and writes the f32 accumulator per pair (20 B moved); {n} target slices, staged path"}
+            "note": f"one launch = the {r} warped neighbours of one side of every target slice ({n} slices of {Y}x{X}); bytes = "
+                    "SURVEY 8(d)'s sweep model, which is also what the kernel moves; per-stage path (fdn_set_option path = 1)"}
 
 
 def check_output(h, vol, out, shape, kernels, params, mean):

@@ -393,7 +393,9 @@ static int build_R_pyramid(fdn_ctx* h, const float* imgs, int nimg, int H, int W
 
 // Farneback level-0 iterations for a batch of pairs whose R planes are in Rstack and whose
 // flows (initial -> final) are in `flow`; M0/M1 are ping-pong scratch for npairs.
-static int run_iterations(fdn_ctx* h, const float* Rstack, float* flow, float* M0, float* M1, PairBatch pb,
+// flow_in: the initial flow (nullptr = zero); flow: receives the result; the two may be the same buffer (cv2 updates its
+// flow in place, seq:98) or different ones (the sweeps keep every step's flow for the one-launch sweep of a side).
+static int run_iterations(fdn_ctx* h, const float* Rstack, const float* flow_in, float* flow, float* M0, float* M1, PairBatch pb,
                           int H, int W, int winsize, int iters)
 {
     if (h->tn.strict_order && !strict_order_supported(W, winsize))
@@ -401,7 +403,12 @@ static int run_iterations(fdn_ctx* h, const float* Rstack, float* flow, float* M
                     "its serial running sum needs; strict mode never falls back silently", W, winsize);
     {
         ScopedTimer t(h, FDN_TIMER_UPDATE_MATRICES);
-        launch_update_matrices(Rstack, flow, M0, pb, H, W, h->stream);
+        launch_update_matrices(Rstack, flow_in, M0, pb, H, W, h->stream);
+    }
+    if (iters <= 0 && flow_in != flow) {       // no iteration: the flow is its initial value
+        const size_t bytes = (size_t)pb.npairs * H * W * 2 * sizeof(float);
+        if (flow_in) FDN_HIP(hipMemcpyAsync(flow, flow_in, bytes, hipMemcpyDeviceToDevice, h->stream));
+        else launch_fill(flow, 0.f, (size_t)pb.npairs * H * W * 2, h->stream);
     }
     float* cur = M0; float* nxt = M1;
     for (int it = 0; it < iters; it++) {
@@ -419,16 +426,17 @@ static int run_iterations(fdn_ctx* h, const float* Rstack, float* flow, float* M
 
 // All levels of calc() for a batch of pairs: coarsest flow = INTER_AREA shrink of the initial flow
 // times the level scale (zeros without one), iterate, INTER_LINEAR to the next finer level times 2.
-// flow_full (n x H x W x 2) holds the initial flow on entry and the result on exit.
-static int pyramid_batch(fdn_ctx* h, const std::vector<PyrLevel>& lv, const float* R0, float* flow_full, float* M0, float* M1,
-                         PairBatch pb, int H, int W, int winsize, int iters, bool has_initial)
+// flow_init (n x H x W x 2, nullptr = none) is the initial flow, flow_full receives the result (they may be one buffer).
+static int pyramid_batch(fdn_ctx* h, const std::vector<PyrLevel>& lv, const float* R0, const float* flow_init, float* flow_full,
+                         float* M0, float* M1, PairBatch pb, int H, int W, int winsize, int iters)
 {
+    const bool has_initial = flow_init != nullptr;
     const int L = (int)lv.size() - 1;
     float* fp = (float*)h->flow_pyr.p;
     const int n = pb.npairs;
     float* fl = fp + lv[L].f_off;
     if (has_initial) {
-        if (resize_dev(h, flow_full, H, W, fl, lv[L].h, lv[L].w, 2, n, 3, true, lv[L].scale)) return -1;
+        if (resize_dev(h, flow_init, H, W, fl, lv[L].h, lv[L].w, 2, n, 3, true, lv[L].scale)) return -1;
     } else {
         launch_fill(fl, 0.f, (size_t)n * lv[L].h * lv[L].w * 2, h->stream);
     }
@@ -437,7 +445,7 @@ static int pyramid_batch(fdn_ctx* h, const std::vector<PyrLevel>& lv, const floa
         if (k < L)
             if (resize_dev(h, fp + lv[k + 1].f_off, lv[k + 1].h, lv[k + 1].w, cur, lv[k].h, lv[k].w, 2, n, 1, true, 2.0)) return -1;
         const float* Rk = k == 0 ? R0 : (const float*)h->Rpyr.p + lv[k].r_off;
-        if (run_iterations(h, Rk, cur, M0, M1, pb, lv[k].h, lv[k].w, winsize, iters)) return -1;
+        if (run_iterations(h, Rk, cur, cur, M0, M1, pb, lv[k].h, lv[k].w, winsize, iters)) return -1;
     }
     return 0;
 }
@@ -479,6 +487,24 @@ static int pyramid_step_fused(fdn_ctx* h, const std::vector<PyrLevel>& lv, const
     ScopedTimer t(h, FDN_TIMER_FUSED);
     launch_farneback_fused(R0, stack, fin, out0, acc, pb, H, W, winsize, iters, weight, h->stream, h->tn, ch, cw);
     return 0;
+}
+
+// Which kernels a sweep runs on: 0 = the 3-iteration fused kernel, 1 = the one-iteration kernel, 2 = one kernel per stage
+static int sweep_path(const fdn_ctx* h, const fdn_sweep_params* p, const std::vector<PyrLevel>& lv, int H, int W)
+{
+    bool fused = fused_supported(p->winsize, p->iters, H, W) && h->tn.path == 0 && !h->tn.strict_order;
+    for (size_t k = 1; k < lv.size(); k++) fused = fused && fused_supported(p->winsize, p->iters, lv[k].h, lv[k].w);
+    if (fused) return 0;
+    // windows the 3-iteration kernel does not cover (winsize >= 10): one launch per iteration, matrices in LDS
+    bool iter = p->iters >= 1 && h->tn.path != 1 && !h->tn.strict_order && iter_supported(p->winsize, H, W);
+    for (size_t k = 1; k < lv.size(); k++) iter = iter && iter_supported(p->winsize, lv[k].h, lv[k].w);
+    return iter ? 1 : 2;
+}
+// bytes of flows (and matrices) per pixel of a target slice on that path: fused / iter: two buffers (16 B), with a pyramid
+// two more per coarser level (22); per-stage: one flow per step of a side (8 r B) + two M sets (40 B)
+static size_t sweep_flow_px(int path, int r, bool pyramid)
+{
+    return path < 2 ? (pyramid ? 22 : 16) : (size_t)8 * std::max(r, 1) + 40 + (pyramid ? 4 : 0);
 }
 
 // One chain step on the one-iteration kernels (fdn_iter.hip): calc()'s levels, coarsest first, `iters` launches each;
@@ -543,16 +569,12 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
 
     PolyConsts pc;
     prepare_poly_consts(p->poly_n, p->poly_sigma, &pc);
-    bool fused = fused_supported(p->winsize, p->iters, H, W) && h->tn.path == 0 && !h->tn.strict_order;
-    for (size_t k = 1; k < lv.size(); k++) fused = fused && fused_supported(p->winsize, p->iters, lv[k].h, lv[k].w);
-    // windows the 3-iteration kernel does not cover (winsize >= 10): one launch per iteration, matrices in LDS
-    bool iter = !fused && p->iters >= 1 && h->tn.path != 1 && !h->tn.strict_order && iter_supported(p->winsize, H, W);
-    for (size_t k = 1; k < lv.size(); k++) iter = iter && iter_supported(p->winsize, lv[k].h, lv[k].w);
+    const int path = sweep_path(h, p, lv, H, W);
+    const bool fused = path == 0, iter = path == 1;
     if (h->tn.path == 2 && !iter) return fail("path 2 (one-iteration kernels) cannot run winsize %d, iters %d here", p->winsize, p->iters);
-    // Scratch of a batch of C target slices, per pixel: the flows -- fused / iter: two buffers (16 B), with a pyramid two
-    // more per coarser level (22); staged: flow 8 B + two M sets 40 B (48, 52) -- and, when a workspace limit is set, the
+    // Scratch of a batch of C target slices, per pixel: the flows (sweep_flow_px) and, when a workspace limit is set, the
     // polynomial expansions too (20 B per slice, 26.7 with a pyramid): R is then rebuilt per batch for its C + 2r slices.
-    const size_t flow_px = fused || iter ? (pyramid ? 22 : 16) : pyramid ? 52 : 48;
+    const size_t flow_px = sweep_flow_px(path, r, pyramid);
     const size_t r_px = pyramid ? 27 : 20;
     const bool limited = h->ws_limit != 0;
     int C;
@@ -577,7 +599,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
         if (ensure(h, h->flow, (size_t)C * HW * 16)) return -1;
         if (pyramid && ensure_flow_pyramid(h, lv, C, 2)) return -1;
     } else {
-        if (ensure(h, h->flow, (size_t)C * HW * 8)) return -1;
+        if (ensure(h, h->flow, (size_t)C * HW * 8 * std::max(r, 1))) return -1;
         if (ensure(h, h->M0, (size_t)C * HW * 20)) return -1;
         if (ensure(h, h->M1, (size_t)C * HW * 20)) return -1;
         if (pyramid && ensure_flow_pyramid(h, lv, C)) return -1;
@@ -635,18 +657,27 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
                 }
                 continue;
             }
-            launch_fill(flow, 0.f, (size_t)n * HW * 2, st);                                              // seq:94,109
+            // per-stage kernels: the flow of every step of the side is kept ([r][n][HW][2]) and the side's warped-
+            // Gaussian sweep runs as ONE launch afterwards, the accumulator in a register (12 B per pixel and pair)
             for (int step = 0; step < r; step++) {
                 int d = side == 0 ? -(step + 1) : (step + 1);
                 PairBatch pb{n, r + c0, d};
-                if (!p->chained && step > 0) launch_fill(flow, 0.f, (size_t)n * HW * 2, st);
+                float* fcur = flow + (size_t)step * C * HW * 2;
+                const float* fprev = p->chained && step > 0 ? flow + (size_t)(step - 1) * C * HW * 2 : nullptr;   // seq:94,109: zero at the chain's start
                 if (pyramid) {
-                    if (pyramid_batch(h, lv, R, flow, M0, M1, pb, H, W, p->winsize, p->iters, p->chained && step > 0)) return -1;
-                } else if (run_iterations(h, R, flow, M0, M1, pb, H, W, p->winsize, p->iters)) return -1;
-                {
-                    ScopedTimer t(h, FDN_TIMER_WARP);
-                    launch_warp_accumulate(stack, flow, acc, pb, H, W, kernel[r + d], st);
-                }
+                    if (pyramid_batch(h, lv, R, fprev, fcur, M0, M1, pb, H, W, p->winsize, p->iters)) return -1;
+                } else if (run_iterations(h, R, fprev, fcur, M0, M1, pb, H, W, p->winsize, p->iters)) return -1;
+            }
+            {
+                ScopedTimer t(h, FDN_TIMER_WARP);
+                std::vector<double> wts(r);
+                for (int step = 0; step < r; step++) wts[step] = kernel[side == 0 ? r - 1 - step : r + 1 + step];
+                // steps of a batch smaller than C are still C * HW * 2 floats apart: one launch per step stride needs
+                // npairs == C, so a short last batch folds step by step
+                if (n == C) launch_sweep_side(stack, flow, acc, PairBatch{n, r + c0, side == 0 ? -1 : 1}, r, 0, H, W, wts.data(), st);
+                else
+                    for (int step = 0; step < r; step++)
+                        launch_sweep_side(stack, flow + (size_t)step * C * HW * 2, acc, PairBatch{n, r + c0, side == 0 ? -1 : 1}, 1, step, H, W, &wts[step], st);
             }
         }
     }
@@ -693,8 +724,9 @@ static int filter_axis_dev(fdn_ctx* h, const float* d_in, float* d_out, int Z, i
     int NP = S;
     if (h->ws_limit) {
         const size_t keep = h->vol_a.cap + h->vol_b.cap + h->vol_in.cap + h->vol_out.cap + h->pair.cap + h->partials.cap + h->area_tab.cap;
-        const bool pyr = p->use_of && pyramid_levels(p->levels, H, W).size() > 1;
-        const size_t sweep_px = !p->use_of ? 0 : (pyr ? 27 : 20) + 52;        // the slower path's flows: an upper bound
+        const std::vector<PyrLevel> lv = pyramid_levels(p->use_of ? p->levels : 0, H, W);
+        const bool pyr = lv.size() > 1;
+        const size_t sweep_px = !p->use_of ? 0 : (pyr ? 27 : 20) + sweep_flow_px(sweep_path(h, p, lv, H, W), r, pyr);
         const size_t per_target = HW * (4 + (axis ? 4 : 0) + sweep_px);
         const size_t fixed = (size_t)2 * r * HW * (4 + (p->use_of ? (pyr ? 27 : 20) : 0)) + (pyr ? std::min<size_t>((size_t)1 << 28, HW * 12 * (size_t)(S + 2 * r)) : 0);
         if (h->ws_limit < keep + fixed + per_target)
@@ -961,8 +993,8 @@ static int farneback_pair_dev(fdn_ctx* h, float* img, float* R, float* flow, flo
     if (lv.size() > 1) {
         if (build_R_pyramid(h, img, 2, H, W, lv, pc)) return -1;
         if (ensure_flow_pyramid(h, lv, 1)) return -1;
-        if (pyramid_batch(h, lv, R, flow, M0, M1, PairBatch{1, 0, 1}, H, W, winsize, iters, (flags & FDN_USE_INITIAL_FLOW) != 0)) return -1;
-    } else if (run_iterations(h, R, flow, M0, M1, PairBatch{1, 0, 1}, H, W, winsize, iters)) return -1;
+        if (pyramid_batch(h, lv, R, (flags & FDN_USE_INITIAL_FLOW) ? flow : nullptr, flow, M0, M1, PairBatch{1, 0, 1}, H, W, winsize, iters)) return -1;
+    } else if (run_iterations(h, R, flow, flow, M0, M1, PairBatch{1, 0, 1}, H, W, winsize, iters)) return -1;
     FDN_HIP(hipGetLastError());
     return 0;
 }

@@ -228,6 +228,10 @@ static __device__ __forceinline__ float2 resize_linear_flow(const float* __restr
 // combines them: remap_issue computes the quantised position and loads, remap_finish weights.
 struct RemapTaps { float v0, v1, v2, v3; int ax, ay; };
 
+// PAIRS: fetch the two taps of a row with one 8-byte load.  Half the gather instructions -- what a memory-bound kernel
+// needs (k_sweep_side: 8.6 -> 6.1 ms) -- for four selects more, which the VALU-bound Farneback kernels cannot afford
+// (k_farneback_fused: 17.0 -> 17.9 ms): those keep the four dword loads.  Same values either way.
+template <bool PAIRS = false>
 static __device__ __forceinline__ void remap_issue(const float* __restrict__ src, int H, int W, int x, int y, float2 f, RemapTaps& r)
 {
     float mx = (float)((double)f.x + (double)x);
@@ -241,8 +245,17 @@ static __device__ __forceinline__ void remap_issue(const float* __restrict__ src
     int xa = clampi(ix, 0, W - 1), xb = clampi(ix + 1, 0, W - 1);
     int ya = clampi(iy, 0, H - 1), yb = clampi(iy + 1, 0, H - 1);
     const unsigned oa = __umul24((unsigned)ya, (unsigned)W), ob = __umul24((unsigned)yb, (unsigned)W);   // H, W < 2^24
-    r.v0 = ld_off<float>(src, (oa + xa) * 4u); r.v1 = ld_off<float>(src, (oa + xb) * 4u);
-    r.v2 = ld_off<float>(src, (ob + xa) * 4u); r.v3 = ld_off<float>(src, (ob + xb) * 4u);
+    if (PAIRS && W >= 2) {
+        // the two taps of a row are neighbours except where the clamp folds them onto one pixel: one 8-byte load of the
+        // pixel pair at clamp(ix, 0, W-2) serves both (half the gather instructions), the fold is a select
+        const int xp = clampi(ix, 0, W - 2);
+        const fdn_v2f pa = ld_off_v2a4(src, (oa + xp) * 4u), pb = ld_off_v2a4(src, (ob + xp) * 4u);
+        r.v0 = xa == xp ? pa.x : pa.y; r.v1 = xb == xp ? pa.x : pa.y;
+        r.v2 = xa == xp ? pb.x : pb.y; r.v3 = xb == xp ? pb.x : pb.y;
+    } else {
+        r.v0 = ld_off<float>(src, (oa + xa) * 4u); r.v1 = ld_off<float>(src, (oa + xb) * 4u);
+        r.v2 = ld_off<float>(src, (ob + xa) * 4u); r.v3 = ld_off<float>(src, (ob + xb) * 4u);
+    }
 }
 
 static __device__ __forceinline__ float remap_finish(const RemapTaps& r)
@@ -256,7 +269,7 @@ static __device__ __forceinline__ float remap_finish(const RemapTaps& r)
 static __device__ __forceinline__ float remap_sample(const float* __restrict__ src, int H, int W, int x, int y, float2 f)
 {
     RemapTaps r;
-    remap_issue(src, H, W, x, y, f, r);
+    remap_issue<false>(src, H, W, x, y, f, r);
     return remap_finish(r);
 }
 

@@ -44,7 +44,7 @@ struct PairBatch {
     int d;       // neighbour offset (signed)
 };
 
-// M[b] = UpdateMatrices(R[t], R[n], flow[b])    (M planar 5 x H x W per pair)
+// M[b] = UpdateMatrices(R[t], R[n], flow[b])    (M planar 5 x H x W per pair; flow == nullptr: zero flow)
 void launch_update_matrices(const float* Rstack, const float* flow, float* M, PairBatch pb,
                             int H, int W, hipStream_t st);
 // flow[b] = solve(box_w(Min[b])); if Mout: Mout[b] = UpdateMatrices(R[t], R[n], flow[b])
@@ -55,9 +55,10 @@ bool launch_update_flow_strict(const float* Rstack, const float* Min, float* Mou
                                int H, int W, int winsize, hipStream_t st);
 void launch_update_flow(const float* Rstack, const float* Min, float* Mout, float* flow,
                         PairBatch pb, int H, int W, int winsize, hipStream_t st);
-// acc[b] = f32( f64(acc[b]) + f64(remap(stack[n], flow[b])) * weight )
-void launch_warp_accumulate(const float* stack, const float* flow, float* acc, PairBatch pb,
-                            int H, int W, double weight, hipStream_t st);
+// The whole side of a pass in one launch: for step s = 0 .. nsteps-1 (nearest neighbour first), neighbour
+// stack[t0 + b + pb.d * (first_step + s + 1)] warped by flows[s][b] and folded into acc[b] with weights[s]; pb.d = -1 / +1.
+void launch_sweep_side(const float* stack, const float* flows, float* acc, PairBatch pb, int nsteps, int first_step,
+                       int H, int W, const double* weights, hipStream_t st);
 // acc[b] = f32( f64(acc[b]) + f64(stack[t0 + b + d]) * weight )   (centre tap, no-OF taps)
 void launch_axpy_slices(const float* stack, float* acc, PairBatch pb, int H, int W,
                         double weight, hipStream_t st);

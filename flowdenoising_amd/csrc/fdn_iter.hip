@@ -17,9 +17,10 @@
 //                                      DESIGN.md 3.2), horizontal window across lanes by doubling through LDS rows,
 //                                      2 x 2 solve, store; on the last iteration of level 0 the 1/32-px remap of the
 //                                      neighbour and acc = f32(f64(acc) + f64(v) w) (seq:106-107)
-//   one s_barrier per row step; the ring holds rows t - 2 MH - 2 .. t (RS = 2 MH + 3 rows x 1280 B): what the
-//   producer writes in step t nobody reads in step t.
-// LDS per workgroup at winsize 15: 21.8 KB ring + 6.4 KB doubling rows = 28.2 KB -> 5 workgroups = 10 waves per CU.
+//   one s_barrier per row step; the ring holds rows t - 2 MH - 1 .. t (RS = 2 MH + 2 rows x 1280 B): the slot the
+//   producer writes in step t held row t - 2 MH - 2, the consumer's trailing row of this step -- which it has read
+//   one step ahead, into registers.
+// LDS per workgroup at winsize 15: 20.0 KB ring + 5.3 KB doubling rows = 25.3 KB -> 6 workgroups = 12 waves per CU.
 #include "fdn_internal.h"
 #include "fdn_device.h"
 
@@ -40,13 +41,16 @@ __global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict_
                                                         double scale, double weight, int nbands, FlowSource fs)
 {
     const int MH = MHT ? MHT : mh_rt;
-    const int RS = 2 * MH + 3;
+    const int RS = 2 * MH + 2;
     const int BW = 64 - 2 * MH;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // ring row: [ (m0, m2) x 64 ][ (m3, m4) x 64 ][ m1 x 64 ] floats; then the consumer's window row: 5 x (64 + 2 MH) doubles
     float* ring = lds;
-    double* xch = (double*)(lds + (size_t)RS * 320);      // [2][5][XP]: the doubling rows (see the consumer)
-    const int XP = 64 + 2 * MH + 2;                       // MH columns of padding on the left, MH + 1 (+1: even) on the right
+    // the doubling rows (see the consumer): [2][XR] doubles, channel c's lane L at MH + 64 c + L.  Reads run up to MH
+    // entries before and MH + 1 after a channel's 64: into the neighbouring channel or the padding at the row's ends --
+    // values that only reach lanes whose results are never used (the band's halo lanes)
+    double* xch = (double*)(lds + (size_t)RS * 320);
+    const int XR = 5 * 64 + 2 * MH + 2;
 
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -136,6 +140,7 @@ __global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict_
         m[0] = p.x; m[2] = p.y; m[3] = q.x; m[4] = q.y; m[1] = row[256 + lane];
     };
     double vs[5] = {0., 0., 0., 0., 0.};
+    float trail[5] = {0.f, 0.f, 0.f, 0.f, 0.f};     // row y - MH - 1 of M, read one step ahead (its slot is rewritten in step t)
     for (int t = 0; t < T; t++) {
         if (t == MH) {   // rows 0 .. MH-1 are in the ring: vsum before row 0 = f32(M[0] (MH + 2)) + rows 1 .. MH-1 (clamped)
             float m[5];
@@ -147,16 +152,17 @@ __global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict_
 #pragma unroll
                 for (int c = 0; c < 5; c++) vs[c] += (double)m[c];
             }
+            ring_row(0, trail);          // row 0's trailing row is row 0 (clamped)
         } else if (t > MH) {
             const int y = t - MH - 1;
             const unsigned o = (unsigned)y * (unsigned)W + (unsigned)xc;
             float acc_old = 0.f;
             if (ACC) acc_old = ld_off<float>(acc, o * 4u);      // does not depend on this step's flow: load it first
-            float lead[5], trail[5];
+            float lead[5];
             ring_row(y + MH < H - 1 ? y + MH : H - 1, lead);
-            ring_row(y - MH - 1 > 0 ? y - MH - 1 : 0, trail);
 #pragma unroll
             for (int c = 0; c < 5; c++) vs[c] += (double)(lead[c] - trail[c]);
+            ring_row(y - MH > 0 ? y - MH : 0, trail);           // the next row's trailing row, while its slot still holds it
             // Horizontal window of 2 MH + 1 columns by doubling: T1 = vsum, T2k[L] = Tk[L] + Tk[L + k] (the sum of 2k
             // columns starting at L); the window is the sum of the Tk of its binary digits, lowest first:
             // winsize 15: v[L+7] + T2[L+5] + T4[L+1] + T8[L-7].  6 additions and 11 LDS accesses per channel where the
@@ -171,9 +177,9 @@ __global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict_
             int pos = MH;                       // column offset of the next term, counted down from the window's right end
             bool first = true;
             for (int k = 1, lvl = 0; k <= 2 * MH + 1; k <<= 1, lvl++) {
-                double* row = xch + (size_t)(lvl & 1) * 5 * XP;
+                double* row = xch + (size_t)(lvl & 1) * XR;
 #pragma unroll
-                for (int c = 0; c < 5; c++) row[c * XP + lane + MH] = tk[c];
+                for (int c = 0; c < 5; c++) row[c * 64 + lane + MH] = tk[c];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const bool digit = ((2 * MH + 1) & k) != 0;
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict_
                 if (digit) pos -= k;            // this digit's block starts at column offset pos + 1
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
-                    const double* r = row + c * XP + lane + MH;
+                    const double* r = row + c * 64 + lane + MH;
                     if (digit) {
                         const double term = r[pos + 1];
                         a[c] = first ? term : a[c] + term;
@@ -215,7 +221,7 @@ bool iter_supported(int winsize, int H, int W)
     return mh >= 1 && mh <= 24 && H >= 2 && W >= 2 && H < (1 << 24) && W < (1 << 24) && (size_t)H * W < ((size_t)1 << 29);
 }
 
-size_t iter_lds_bytes(int mh) { return (size_t)(2 * mh + 3) * 320 * sizeof(float) + (size_t)2 * 5 * (64 + 2 * mh + 2) * sizeof(double); }
+size_t iter_lds_bytes(int mh) { return (size_t)(2 * mh + 2) * 320 * sizeof(float) + (size_t)2 * (5 * 64 + 2 * mh + 2) * sizeof(double); }
 
 template <int MHT>
 static int launch_iter_t(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc, PairBatch pb,

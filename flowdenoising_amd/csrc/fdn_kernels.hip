@@ -124,14 +124,14 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict
     const int b = blockIdx.z;
     const RImage R0 = r_image(Rstack + (size_t)(pb.t0 + b) * 5 * HW, HW);
     const RImage R1 = r_image(Rstack + (size_t)(pb.t0 + b + pb.d) * 5 * HW, HW);
-    const float2* flow = (const float2*)flow_base + (size_t)b * HW;
+    const float2* flow = flow_base ? (const float2*)flow_base + (size_t)b * HW : nullptr;   // nullptr: zero initial flow
     float* M = M_base + (size_t)b * 5 * HW;
     int x = blockIdx.x * 64 + (threadIdx.x & 63);
     int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     size_t o = (size_t)y * W + x;
     float m[5];
-    float2 f = flow[o];
+    float2 f = flow ? flow[o] : make_float2(0.f, 0.f);
     compute_M(R0, R1, H, W, x, y, f.x, f.y, m);
 #pragma unroll
     for (int c = 0; c < 5; c++) M[c * HW + o] = m[c];
@@ -450,28 +450,68 @@ void launch_update_flow(const float* Rstack, const float* Min, float* Mout, floa
 // cv2.remap INTER_LINEAR / BORDER_REPLICATE: coordinates rounded half-even to 1/32 px,
 // weights (1-a/32)(1-b/32)..., four clamped taps, f32 left-to-right sum.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_warp_accumulate(const float* __restrict__ stack, const float* __restrict__ flow_base,
-                                                         float* __restrict__ acc_base, PairBatch pb, int H, int W, double weight)
+// ---------------------------------------------------------------------------------
+// The warped-Gaussian sweep of one side of a pass as ONE kernel (flow 8 + neighbour 4 bytes per pixel
+// and pair, the accumulator read and written once): for every target of the batch, the `nsteps` neighbours on one
+// side in the reference's order (nearest first, seq:95 / seq:110), each warped by its own flow (seq:106) and folded
+// into the accumulator, acc = f32(f64(acc) + f64(v) w) (seq:107) -- the accumulator stays in a register.
+// flows: [nsteps][npairs][H][W][2] (the flows of a chain are all kept by the per-stage path).
+// Loads of U steps are issued together (flows, then their 4 taps each) before the serial fold.
+// ---------------------------------------------------------------------------------
+constexpr int SWEEP_MAX_STEPS = 48;
+struct SweepWeights { double w[SWEEP_MAX_STEPS]; };
+
+template <int U>
+__global__ __launch_bounds__(256) void k_sweep_side(const float* __restrict__ stack, const float* __restrict__ flows,
+                                                    float* __restrict__ acc_base, PairBatch pb, int nsteps, int first_step,
+                                                    int H, int W, SweepWeights sw)
 {
     const size_t HW = (size_t)H * W;
     const int b = blockIdx.z;
-    const float* src = stack + (size_t)(pb.t0 + b + pb.d) * HW;
-    const float2* flow = (const float2*)flow_base + (size_t)b * HW;
-    float* acc = acc_base + (size_t)b * HW;
-    int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
-    size_t o = (size_t)y * W + x;
-    float v = remap_sample(src, H, W, x, y, flow[o]);
-    acc[o] = (float)((double)acc[o] + (double)v * weight);
+    const size_t o = (size_t)y * W + x;
+    float* acc = acc_base + (size_t)b * HW;
+    float a = acc[o];
+    const size_t step_stride = (size_t)pb.npairs * HW;     // float2 elements between consecutive steps' flows
+    const float2* fl = (const float2*)flows + (size_t)b * HW + o;
+    const int dir = pb.d;                                   // -1: the back side, +1: the forward side
+    for (int s0 = 0; s0 < nsteps; s0 += U) {
+        float2 f[U];
+        RemapTaps t[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int s = s0 + u < nsteps ? s0 + u : nsteps - 1;
+            f[u] = fl[(size_t)s * step_stride];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int s = s0 + u < nsteps ? s0 + u : nsteps - 1;
+            const float* src = stack + (size_t)(pb.t0 + b + dir * (first_step + s + 1)) * HW;
+            remap_issue<true>(src, H, W, x, y, f[u], t[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (s0 + u < nsteps) a = (float)((double)a + (double)remap_finish(t[u]) * sw.w[s0 + u]);
+    }
+    acc[o] = a;
 }
 
-void launch_warp_accumulate(const float* stack, const float* flow, float* acc, PairBatch pb, int H, int W,
-                            double weight, hipStream_t st)
+// acc[b] <- fold of steps first_step .. first_step + nsteps - 1 of side pb.d (= -1 or +1); weights[s] belongs to step
+// first_step + s; flows points at step first_step's flows.
+void launch_sweep_side(const float* stack, const float* flows, float* acc, PairBatch pb, int nsteps, int first_step,
+                       int H, int W, const double* weights, hipStream_t st)
 {
     if (pb.npairs <= 0) return;
     dim3 grid((W + 63) / 64, (H + 3) / 4, pb.npairs);
-    hipLaunchKernelGGL(k_warp_accumulate, grid, dim3(256), 0, st, stack, flow, acc, pb, H, W, weight);
+    const size_t step_stride = (size_t)pb.npairs * H * W * 2;
+    for (int s0 = 0; s0 < nsteps; s0 += SWEEP_MAX_STEPS) {
+        const int n = nsteps - s0 < SWEEP_MAX_STEPS ? nsteps - s0 : SWEEP_MAX_STEPS;
+        SweepWeights sw;
+        for (int i = 0; i < n; i++) sw.w[i] = weights[s0 + i];
+        hipLaunchKernelGGL(k_sweep_side<8>, grid, dim3(256), 0, st, stack, flows + (size_t)s0 * step_stride, acc, pb, n, first_step + s0, H, W, sw);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_warp(const float* __restrict__ src, const float* __restrict__ flow_base,
