@@ -104,9 +104,16 @@ def _run_sharded(args, shape, kernels, l, w):
     from .operators import _params
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", rank))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", device_id=dev)
+    if torch.cuda.device_count() >= world:          # one GPU per rank, exchanges over RCCL / xGMI
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        dist.init_process_group("nccl", device_id=dev)
+    else:                                           # fewer GPUs than ranks (a rehearsal box): share GPU 0, exchanges staged over gloo
+        local = 0
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("gloo")
+        logging.warning(f"--gpus {world} on a node with {torch.cuda.device_count()} GPU(s): the ranks share GPU 0")
     plan = SlabPlan(shape, world, rank)
     mine = np.ascontiguousarray(fio.read_slab(args.input, plan.z0, plan.z0 + plan.zlen), dtype=np.float32)   # seq:517
     slab = torch.from_numpy(mine).to(dev)
@@ -114,18 +121,11 @@ def _run_sharded(args, shape, kernels, l, w):
     h.set_stream(torch.cuda.current_stream().cuda_stream)
     border = _lib.BORDER_WRAP if args.compat == "par" else _lib.BORDER_MEAN_PAD
     params = _params(l, w, use_of=not args.no_OF, border_mode=border, chained=not args.recompute_flow)
-    out = SlabEngine(plan, h, dist).filter_3d(slab, kernels, params)
-    res = None
-    if rank == 0:                       # slabs may differ in length: point-to-point into their place, rank 0 only
-        full = torch.empty(tuple(shape), dtype=torch.float32, device=dev)
-        full[plan.z0:plan.z0 + plan.zlen].copy_(out)
-        ops = [dist.P2POp(dist.irecv, full[s:e], r) for r, (s, e) in enumerate(plan.parts[0]) if r != 0]
-        for wk in (dist.batch_isend_irecv(ops) if ops else []):
-            wk.wait()
-        res = full.cpu().numpy()
-    else:
-        for wk in dist.batch_isend_irecv([dist.P2POp(dist.isend, out.contiguous(), 0)]):
-            wk.wait()
+    eng = SlabEngine(plan, h, dist)
+    out = eng.filter_3d(slab, kernels, params)
+    full = eng.gather_z_slabs(out, 0)               # slabs may differ in length: point-to-point into their place, rank 0 only
+    res = full.cpu().numpy() if rank == 0 else None
+    logging.info(f"rank {rank} phases (ms): " + ", ".join(f"{k} {v:.1f}" for k, v in eng.phase_times().items()))
     dist.barrier()
     dist.destroy_process_group()
     return res

@@ -142,6 +142,9 @@ static __device__ __forceinline__ void finish_M_p(fdn_v2f r01, fdn_v2f r23, floa
                                                   bool damp, fdn_v2f& m02, float& m1, fdn_v2f& m34)
 {
     const bool inside = (unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1);
+    // (splatting each weight over a channel pair costs the compiler two moves per weight; writing the eight products as
+    // v_pk_mul_f32 with op_sel by hand removes 18 of the fused kernel's 734 instructions per row and changes nothing
+    // measurable: 17.1 -> 17.2 ms)
     const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
     const fdn_v2f s01 = a00 * g.a0[0] + a01 * g.b0[0] + a10 * g.a1[0] + a11 * g.b1[0];
     const fdn_v2f s23 = a00 * g.a0[1] + a01 * g.b0[1] + a10 * g.a1[1] + a11 * g.b1[1];

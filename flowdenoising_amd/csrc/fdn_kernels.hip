@@ -781,6 +781,44 @@ __global__ __launch_bounds__(256) void k_resize_area_int(const float* __restrict
         dst[((size_t)dy * dw + dx) * CN + ch] = v;
     }
 }
+// The same for a 2-channel image (a flow) shrunk by ISX = 2, 4, 8 or 16 in x -- calc()'s coarsest-level initial flow,
+// once per chain step: lanes sit on SOURCE columns so that every source row is one coalesced read (a thread per output
+// pixel reads 8-byte pieces 8 ISX bytes apart: 3.2 ms per 512 x 1024^2 flows, 1.35 TB/s).  The arithmetic does not
+// change: one f32 chain per output pixel over its block in row-major order.  Along a row the chain hops from lane to
+// lane (t = t[lane - 1] + p, a DPP row_shr:1 add; after step s the block's lane s holds the chain through column s),
+// the row's end is handed to the block's first lane for the next row (row_shl:ISX-1).
+template <int ISX>
+__global__ __launch_bounds__(256) void k_resize_area_flow(const float2* __restrict__ in, int sh, int sw, float2* __restrict__ out,
+                                                          int dh, int dw, int isy, int apply_ps, double ps)
+{
+    const int lane = threadIdx.x & 63;
+    const int sx = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
+    if (sx - lane >= sw) return;                  // the whole wave is past the row
+    const int dy = blockIdx.y;
+    const bool live = sx < sw;
+    const float2* src = in + (size_t)blockIdx.z * sh * sw + (size_t)dy * isy * sw + (live ? sx : sw - 1);
+    float tx = 0.f, ty = 0.f;
+    for (int ky = 0; ky < isy; ky++) {
+        const float2 p = src[(size_t)ky * sw];
+        // the chain so far: the previous row's end sits ISX-1 lanes up; nothing before the first row
+        float cx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tx), 0x100 + ISX - 1, 0xf, 0xf, true));
+        float cy = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ty), 0x100 + ISX - 1, 0xf, 0xf, true));
+        if (ky == 0) { cx = 0.f; cy = 0.f; }
+        tx = cx + p.x; ty = cy + p.y;
+#pragma unroll
+        for (int s = 1; s < ISX; s++) {
+            tx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tx), 0x111, 0xf, 0xf, true)) + p.x;
+            ty = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ty), 0x111, 0xf, 0xf, true)) + p.y;
+        }
+    }
+    if (live && (lane & (ISX - 1)) == ISX - 1) {
+        const float scale = 1.f / (float)(ISX * isy);
+        float vx = tx * scale, vy = ty * scale;
+        if (apply_ps) { vx = (float)((double)vx * ps); vy = (float)((double)vy * ps); }
+        out[(size_t)blockIdx.z * dh * dw + (size_t)dy * dw + sx / ISX] = make_float2(vx, vy);
+    }
+}
+
 // INTER_AREA, any shrink ratio (cv::resizeArea_ with computeResizeAreaTab): per output pixel,
 // rows in table order: buf = sum_k S[sy][sx_k] * alpha_k (f32, left to right, starting from 0),
 // then sum = beta_0 * buf_0, sum += beta_j * buf_j.  Tables: tab_si/tab_alpha with CSR offsets.
@@ -840,7 +878,13 @@ void resize_images(const float* in, int sh, int sw, float* out, int dh, int dw, 
     int isx = (int)scale_x, isy = (int)scale_y;
     bool integer = fabs(scale_x - isx) < 2.220446049250313e-16 && fabs(scale_y - isy) < 2.220446049250313e-16;
     if (interp == 1 && integer && isx == 2 && isy == 2) interp = 3;
-    if (interp == 3 && scale_x >= 1 && scale_y >= 1 && integer) {
+    if (interp == 3 && scale_x >= 1 && scale_y >= 1 && integer && cn == 2 && (isx == 2 || isx == 4 || isx == 8 || isx == 16)) {
+        dim3 g((sw + 255) / 256, dh, nimg);
+        const float2* i2 = (const float2*)in; float2* o2 = (float2*)out;
+#define FDN_AREA_FLOW(N) hipLaunchKernelGGL(k_resize_area_flow<N>, g, dim3(256), 0, st, i2, sh, sw, o2, dh, dw, isy, (int)apply_ps, ps)
+        if (isx == 2) FDN_AREA_FLOW(2); else if (isx == 4) FDN_AREA_FLOW(4); else if (isx == 8) FDN_AREA_FLOW(8); else FDN_AREA_FLOW(16);
+#undef FDN_AREA_FLOW
+    } else if (interp == 3 && scale_x >= 1 && scale_y >= 1 && integer) {
         if (cn == 1) hipLaunchKernelGGL(k_resize_area_int<1>, grid, dim3(256), 0, st, in, sh, sw, out, dh, dw, isx, isy, (int)apply_ps, ps);
         else hipLaunchKernelGGL(k_resize_area_int<2>, grid, dim3(256), 0, st, in, sh, sw, out, dh, dw, isx, isy, (int)apply_ps, ps);
     } else {

@@ -149,9 +149,6 @@ class HipBackend:
             return
         self.h.permute_dev(src_view.data_ptr(), dst.data_ptr(), tuple(src_view.shape), tuple(st))
 
-    def local_sum(self, t):
-        return self.h.sum_dev(t.data_ptr(), t.numel())
-
     def chunk_sums(self, t):
         return self.h.np_chunk_sums_dev(t.data_ptr(), t.numel())
 
@@ -379,6 +376,19 @@ class SlabEngine:
             got = self._all_gather(buf)
             allsums = np.concatenate([g[:n].cpu().numpy() for g, n in zip(got, per)])
             return np.float32(np.cumsum(allsums, dtype=np.float32)[-1] / np.float32(ntot))
+
+    def gather_z_slabs(self, slab, dst=0):
+        """The whole volume on rank `dst` (None on the others): every rank sends its Z-slab there and only there."""
+        torch, plan, me = self.torch, self.plan, self.plan.rank
+        if plan.world == 1 or self.dist is None:
+            return slab
+        if me != dst:
+            self._p2p([], [(slab.contiguous(), dst)])
+            return None
+        full = torch.empty(plan.shape, dtype=slab.dtype, device=slab.device)
+        full[plan.z0:plan.z0 + plan.zlen].copy_(slab)
+        self._p2p([(full[s:e], r) for r, (s, e) in enumerate(plan.parts[0]) if r != dst], [])
+        return full
 
     # -- the filter ------------------------------------------------------------------------
     def filter_3d(self, vol, kernels, params, mean=None):

@@ -27,9 +27,6 @@ class OracleBackend:
     def pack(self, src_view, dst):
         dst.copy_(src_view)
 
-    def local_sum(self, t):
-        return float(t.numpy().astype(np.float64).sum())
-
     def chunk_sums(self, t):
         a = t.numpy().reshape(-1)      # numpy's own pairwise sum of each 8192-element chunk
         return np.array([a[s:s + 8192].sum(dtype=np.float32) for s in range(0, a.size, 8192)], dtype=np.float32)
@@ -63,19 +60,11 @@ def _worker(rank, world, port, shape, sigmas, border_mode, use_of, q):
         out = eng.filter_3d(slab, kernels, params, mean=vol.mean())      # second step: the persistent buffers are reused
         assert torch.equal(first, out)
         assert set(eng.phase_times()) == set(eng.PHASES) and eng.phase_times()["compute"] > 0
-        gathered = [torch.empty((e - s,) + tuple(shape[1:]), dtype=torch.float32) for s, e in plan.parts[0]]
-        dist.all_gather(gathered, out) if len({g.shape for g in gathered}) == 1 else _gather_uneven(dist, gathered, out, rank)
+        full = eng.gather_z_slabs(out, 0)
         if rank == 0:
-            q.put((torch.cat(gathered).numpy(), float(mean_auto)))
+            q.put((full.numpy().copy(), float(mean_auto)))
     finally:
         dist.destroy_process_group()
-
-
-def _gather_uneven(dist, gathered, out, rank):
-    for r, g in enumerate(gathered):
-        if r == rank:
-            g.copy_(out)
-        dist.broadcast(g, src=r)
 
 
 def _run(world, shape, sigmas, border_mode=0, use_of=True):
