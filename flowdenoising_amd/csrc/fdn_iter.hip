@@ -169,8 +169,10 @@ __global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict_
             // plain window takes 14 and 16 (and 150 registers when unrolled).  Two LDS rows per channel, recycled:
             // a wave's LDS operations execute in order, so a row may be rewritten once the reads of its previous
             // content have been issued; the fences only keep the compiler from reordering across them.
-            // (Splitting the row into pipeline stages over consecutive steps -- window sums, solve + tap issue,
-            // weighting -- measured 6 % slower: the step is not bound by this chain.)
+            // (Measured and rejected, all bit-identical: splitting the row into pipeline stages over consecutive steps
+            // -- window sums / solve + tap issue / weighting -- 6 % slower; only deferring the remap taps' weighting to
+            // the next step, the loop unrolled by two for the alternating tap registers: 6 % slower; two neighbouring
+            // bands per workgroup so that their shared columns come from HBM once: 5 % slower, four waves per barrier.)
             double a[5], tk[5];
 #pragma unroll
             for (int c = 0; c < 5; c++) tk[c] = vs[c];

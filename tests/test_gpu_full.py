@@ -156,6 +156,29 @@ def test_workspace_limit_bounds_every_buffer(fdn, oracle, l, w):
     assert rel_err(got, oracle.OF_filter(vol, ks, l, w, nthreads=8)) < TIGHT_TOL
 
 
+@pytest.mark.parametrize("shape,sig,border,use_of", [((3, 40, 70), 1.0, 1, True), ((5, 36, 40), 1.5, 0, False), ((4, 34, 36), 1.0, 1, False)])
+def test_workspace_limit_with_wrapped_ends_and_short_axes(fdn, oracle, shape, sig, border, use_of):
+    """Chunked passes where the halo (K//2 = 4 or 6 slices) is longer than the axis and the ends wrap around (par:312)
+    or the plain Gaussian runs (-n): same bits as the unchunked pass and as the oracle."""
+    from flowdenoising_amd import _lib
+    from flowdenoising_amd.operators import _params, handle
+    vol = _vol(shape, seed=19)
+    ks = [fdn.get_gaussian_kernel(sig)] * 3
+    p = _params(0, 5, use_of, border, True)
+    h = handle()
+    want = h.filter_3d(vol, ks, vol.mean(), p)
+    h.set_workspace_limit(3 * vol.nbytes + (1 << 20))
+    try:
+        got = h.filter_3d(vol, ks, vol.mean(), p)
+        assert h.workspace_bytes() <= 3 * vol.nbytes + (1 << 20)
+    finally:
+        h.set_workspace_limit(0)
+    assert np.array_equal(got, want)
+    ref = oracle.OF_filter(vol, ks, 0, 5, border_mode=border, nthreads=8) if use_of else None
+    if use_of:
+        assert rel_err(got, ref) < TIGHT_TOL
+
+
 def test_config2_under_a_16_gib_workspace_limit(fdn):
     """configs[2] (2 GiB volume, 26 GiB of scratch when unlimited) completes bit-equal when the handle may own 16 GiB."""
     import torch
