@@ -167,12 +167,21 @@ def test_workspace_limit_with_wrapped_ends_and_short_axes(fdn, oracle, shape, si
     p = _params(0, 5, use_of, border, True)
     h = handle()
     want = h.filter_3d(vol, ks, vol.mean(), p)
-    h.set_workspace_limit(3 * vol.nbytes + (1 << 20))
+    from flowdenoising_amd._lib import FlowdnError
+    done = 0
     try:
-        got = h.filter_3d(vol, ks, vol.mean(), p)
-        assert h.workspace_bytes() <= 3 * vol.nbytes + (1 << 20)
+        for limit in (4 << 20, 2 << 20, 1200 << 10, 1000 << 10, 900 << 10, 800 << 10, 600 << 10, 400 << 10):    # ever fewer slices per chunk
+            h.set_workspace_limit(limit)
+            try:
+                got = h.filter_3d(vol, ks, vol.mean(), p)
+            except FlowdnError as e:
+                assert "too small" in str(e)
+                break
+            assert h.workspace_bytes() <= limit and np.array_equal(got, want), limit
+            done += 1
     finally:
         h.set_workspace_limit(0)
+    assert done >= 2
     assert np.array_equal(got, want)
     ref = oracle.OF_filter(vol, ks, 0, 5, border_mode=border, nthreads=8) if use_of else None
     if use_of:
