@@ -599,6 +599,58 @@ static void update_flow_blur(const float* R0, const float* R1, float* flow, floa
         if (update) update_matrices(R0, R1, flow, M, H, W, 0, H);
         return;
     }
+    if (box_mode == 3) {
+        /* OpenCV's vertical running sum, the horizontal window summed BY DOUBLING -- the order of the HIP path's
+         * one-iteration kernel (fdn_iter.hip, winsize >= 10): T1 = vsum (columns clamped to the image), T2k[x] = Tk[x] +
+         * Tk[x + k]; the window [x - m, x + m] is the sum of the Tk of the binary digits of 2m + 1, lowest digit
+         * first and rightmost block first: w = 15: T1[x+7] + T2[x+5] + T4[x+1] + T8[x-7].  Exact -- hence equal to
+         * every other order -- whenever the f64 sums do not round. */
+        int wn = 2 * m + 1, nlev = 0;
+        while ((1 << nlev) <= wn) nlev++;
+        int ext = W + 4 * m + 4;                        /* columns -m .. W-1+m plus room for the T builds */
+        double* T = (double*)malloc((size_t)nlev * ext * 5 * sizeof(double));
+        double* vs = (double*)malloc((size_t)W * 5 * sizeof(double));
+        for (int x = 0; x < W * 5; x++) vs[x] = M[x] * (m + 2);
+        for (int y = 1; y < m; y++) {
+            const float* srow = M + (size_t)(y < H - 1 ? y : H - 1) * W * 5;
+            for (int x = 0; x < W * 5; x++) vs[x] += srow[x];
+        }
+        for (int y = 0; y < H; y++) {
+            float* fl = flow + (size_t)y * W * 2;
+            const float* s0 = M + (size_t)(y - m - 1 > 0 ? y - m - 1 : 0) * W * 5;
+            const float* s1 = M + (size_t)(y + m < H - 1 ? y + m : H - 1) * W * 5;
+            for (int x = 0; x < W * 5; x++) vs[x] += s1[x] - s0[x];
+            /* level arrays over extended columns e = x + m, x = -m .. : T[lev][e] */
+            for (int e = 0; e < ext; e++)
+                for (int c = 0; c < 5; c++) T[((size_t)0 * ext + e) * 5 + c] = vs[clampi(e - m, 0, W - 1) * 5 + c];
+            for (int lev = 1; lev < nlev; lev++) {
+                int k = 1 << (lev - 1);
+                for (int e = 0; e < ext; e++)
+                    for (int c = 0; c < 5; c++) {
+                        int e2 = e + k < ext ? e + k : ext - 1;
+                        T[((size_t)lev * ext + e) * 5 + c] = T[((size_t)(lev - 1) * ext + e) * 5 + c] + T[((size_t)(lev - 1) * ext + e2) * 5 + c];
+                    }
+            }
+            for (int x = 0; x < W; x++) {
+                double a[5];
+                int pos = m, first = 1;
+                for (int lev = 0; lev < nlev; lev++) {
+                    int k = 1 << lev;
+                    if (!(wn & k)) continue;
+                    pos -= k;
+                    for (int c = 0; c < 5; c++) {
+                        double term = T[((size_t)lev * ext + (x + pos + 1 + m)) * 5 + c];
+                        a[c] = first ? term : a[c] + term;
+                    }
+                    first = 0;
+                }
+                solve_flow(a[0], a[1], a[2], a[3], a[4], scale, fl + x * 2);
+            }
+        }
+        free(T); free(vs);
+        if (update) update_matrices(R0, R1, flow, M, H, W, 0, H);
+        return;
+    }
     int y0 = 0, y1;
     int min_update_stripe = (1 << 10) / W > block_size ? (1 << 10) / W : block_size;
     double* _vsum = (double*)malloc((size_t)(W + m * 2 + 2) * 5 * sizeof(double));

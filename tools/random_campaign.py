@@ -1,4 +1,5 @@
-"""One-off randomised parity campaign: many more random sweep configurations than the test suite holds."""
+"""One-off randomised parity campaign: many more random sweep configurations than the test suite holds.
+usage: random_campaign.py [n] [seed] [wide]   -- `wide`: windows 10 .. 31 (the one-iteration kernel) instead of 3 .. 15"""
 import sys, importlib.util, numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 spec = importlib.util.spec_from_file_location("tp", "tests/test_gpu_parity.py"); tp = importlib.util.module_from_spec(spec); spec.loader.exec_module(tp)
@@ -8,6 +9,10 @@ oracle.build()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 bad = 0; exact = 0; order = 0
 cases = tp._random_cases(n, int(sys.argv[2]) if len(sys.argv) > 2 else 777)
+if len(sys.argv) > 3 and sys.argv[3] == "wide":
+    rng = np.random.default_rng(99)
+    cases = [(shape, axis, l, int(rng.choice([10, 11, 13, 15, 15, 17, 21, 31])), sigma, border, chained, seed)
+             for (shape, axis, l, w, sigma, border, chained, seed) in cases]
 for i, (shape, axis, l, w, sigma, border, chained, seed) in enumerate(cases):
     vol = tp._vol(shape, seed=seed)
     k = fdn.get_gaussian_kernel(sigma)
@@ -18,7 +23,7 @@ for i, (shape, axis, l, w, sigma, border, chained, seed) in enumerate(cases):
     if np.array_equal(got, want):
         exact += 1
     else:
-        want2 = oracle.filter_along_axis(vol, axis, k, l, w, mean, border_mode=border, chained=chained, box_mode=2, nthreads=8)
+        want2 = oracle.filter_along_axis(vol, axis, k, l, w, mean, border_mode=border, chained=chained, box_mode=3 if w >= 10 else 2, nthreads=8)
         err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
         kind = "f64 summation order only" if np.array_equal(got, want2) else "REAL MISMATCH"
         print(kind, (shape, axis, l, w, sigma, border, chained, seed), err, flush=True)
