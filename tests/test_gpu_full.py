@@ -67,6 +67,28 @@ def test_cli_gpus_2_shards_reads_and_gathers(fdn, tmp_path):
     assert np.array_equal(fio.read_mrc(str(tmp_path / "two.mrc")), fio.read_mrc(str(tmp_path / "one.mrc")))
 
 
+def test_bench_line_contract(fdn):
+    """bench.py on a small volume: ONE JSON line with the contract's keys, a roofline fraction that is a fraction, the
+    post-run oracle check green and a CPU baseline beside it."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--shape", "24,96,160", "--steps", "1", "--warmup", "1",
+                        "--cpu-targets", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "checked"):
+        assert key in d, key
+    assert d["unit"] == "Mvoxels/s" and d["dtype"] == "f32" and d["vs_baseline"] is None and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["kernel"] == "k_farneback_fused" and 0 < rf["frac"] <= 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["traffic"] is None            # the committed PMC pass is for the 512 x 1024 x 1024 workload, not this one
+    assert d["checked"]["ok"] and d["checked"]["bit_equal"] and d["checked"]["timed_output_equals_pass_by_pass_rerun"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert 0 < d["sweep"]["frac"] <= 1
+
+
 def test_flowdenoising_class_mirrors_par(fdn, oracle):
     vol = _vol((8, 34, 36), seed=6)
     ks = [fdn.get_gaussian_kernel(0.5)] * 3

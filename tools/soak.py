@@ -11,7 +11,7 @@ vol = make_volume((48, 1024, 1024), seed=77, amplitude=100.0)
 k = fd.get_gaussian_kernel(2.0)
 ref = None
 for it in range(6):
-    out = fd.OF_filter_along_Z(vol, k, int(sys.argv[1]), 5, vol.mean())
+    out = fd.OF_filter_along_Z(vol, k, int(sys.argv[1]), int(sys.argv[3]), vol.mean())
     if ref is None: ref = out
     assert np.array_equal(ref, out), ("run", it)
 np.save(sys.argv[2], ref)
@@ -22,8 +22,16 @@ for l in (0, 3):
     for occ in ("3", "4", "5"):
         fn = f"/tmp/soak_{l}_{occ}.npy"
         env = dict(os.environ, FDN_FUSED_OCC=occ)
-        subprocess.run([sys.executable, "-c", code, str(l), fn], env=env, check=True)
+        subprocess.run([sys.executable, "-c", code, str(l), fn, "5"], env=env, check=True)
         outs.append((l, fn))
+# the one-iteration kernel (winsize 15): its own runs, and against the per-stage kernels
+for l in (0, 3):
+    fns = []
+    for path in ("0", "1"):
+        fn = f"/tmp/soak_w15_{l}_{path}.npy"
+        subprocess.run([sys.executable, "-c", code, str(l), fn, "15"], env=dict(os.environ, FDN_PATH=path), check=True)
+        fns.append(fn)
+    assert np.array_equal(np.load(fns[0]), np.load(fns[1])), ("w15", l)
 for l in (0, 3):
     a = [np.load(fn) for ll, fn in outs if ll == l]
     assert all(np.array_equal(a[0], b) for b in a[1:]), l
