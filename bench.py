@@ -254,11 +254,17 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
+    rehearsal = world > 1 and torch.cuda.device_count() < world
+    if rehearsal:            # fewer GPUs than ranks (a one-GPU box): the ranks share GPU 0 and exchange through the host
+        local_rank = 0       # over gloo -- exercises every line of the N > 1 path, its numbers mean nothing
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     shape = tuple(int(v) for v in a.shape.split(","))
     Z, Y, X = shape
@@ -292,7 +298,9 @@ def main():
         def step():
             return eng.filter_3d(vol, kernels, params)
         out = None
-        parallelism = f"{world} Z-slabs, halo exchange + all-to-all repartition per pass (RCCL)"
+        parallelism = f"{world} Z-slabs, one exchange per pass (halos + repartition, point-to-point over RCCL)"
+        if rehearsal:
+            parallelism = f"REHEARSAL: {world} ranks sharing one GPU, exchanges staged through the host over gloo (not a measurement)"
 
     for _ in range(a.warmup):
         step()
@@ -315,7 +323,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     timers = h.timers() if not a.no_timers else {}
@@ -323,7 +331,7 @@ def main():
     if eng is not None and hasattr(eng, "phase_times") and not a.no_timers:
         mine = eng.phase_times()          # ms per category on this rank, over the timed steps
         names = sorted(mine)
-        buf = torch.tensor([mine[n] for n in names], dtype=torch.float64, device=dev)
+        buf = torch.tensor([mine[n] for n in names], dtype=torch.float64, device="cpu" if rehearsal else dev)
         allr = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(allr, buf)
         phases = {n: [round(float(r[i]) / a.steps, 2) for r in allr] for i, n in enumerate(names)}
