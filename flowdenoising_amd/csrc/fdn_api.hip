@@ -383,8 +383,12 @@ static int build_R_pyramid(fdn_ctx* h, const float* imgs, int nimg, int H, int W
         prepare_blur_taps(lv[k].smooth_sz, lv[k].sigma, &bt);
         for (int s0 = 0; s0 < nimg; s0 += chunk) {
             int n = std::min(chunk, nimg - s0);
-            launch_gaussian_blur(imgs + (size_t)s0 * HW, tmp, blurred, n, H, W, bt, h->stream);
-            if (resize_dev(h, blurred, H, W, small, lv[k].h, lv[k].w, 1, n, 1, false, 1.0)) return -1;
+            if (lv[k].h < H && lv[k].w < W) {     // always, for a pyramid level: blur only where the resize reads
+                launch_blur_resize(imgs + (size_t)s0 * HW, tmp, small, n, H, W, lv[k].h, lv[k].w, bt, h->stream);
+            } else {
+                launch_gaussian_blur(imgs + (size_t)s0 * HW, tmp, blurred, n, H, W, bt, h->stream);
+                if (resize_dev(h, blurred, H, W, small, lv[k].h, lv[k].w, 1, n, 1, false, 1.0)) return -1;
+            }
             launch_polyexp(small, (float*)h->Rpyr.p + lv[k].r_off + (size_t)s0 * 5 * lv[k].h * lv[k].w, n, lv[k].h, lv[k].w, pc, h->stream);
         }
     }

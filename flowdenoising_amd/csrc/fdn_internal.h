@@ -113,6 +113,10 @@ int launch_sum_partials(const float* in, size_t count, double* partials, int max
 // pyramid pieces (levels > 0)
 void launch_gaussian_blur(const float* in, float* tmp, float* out, int nimg, int H, int W,
                           const BlurTaps& bt, hipStream_t st);
+// small = resize(GaussianBlur(in, bt), (dw, dh), INTER_LINEAR) with the blur evaluated only where the resize reads it
+// (a strict shrink: dw < W, dh < H); tmp: nimg * H * 2 dw floats
+void launch_blur_resize(const float* in, float* tmp, float* small, int nimg, int H, int W, int dh, int dw,
+                        const BlurTaps& bt, hipStream_t st);
 // cv::resize as FarnebackOpticalFlowImpl::calc uses it, nimg images of cn interleaved
 // channels: interp 1 = INTER_LINEAR (an exact 2x2 shrink is promoted to area, as cv::resize
 // does), 3 = INTER_AREA (integer ratios on this path).  If apply_ps, each result is then

@@ -85,9 +85,10 @@ __global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict_
         const float xf = (float)xc;
         // Operands of a row arrive in two dependent hops: its flow and R0, then -- at the position the flow points to --
         // the bilinear footprint of R1.  Three register sets rotate (the loop is unrolled by three) so that neither
-        // hop is waited for in the step that issues it: step t loads flow/R0 of row t + 4, issues the gather of row
-        // t + 2 (whose flow was loaded two steps earlier) and turns row t into M.  (A register copy at the end of a step
-        // would make the wave wait for the loads right away.)
+        // hop is waited for in the step that issues it: step t loads flow/R0 of row t + 2, issues the gather of row
+        // t + 1 (whose flow was loaded a step earlier) and turns row t into M.  (A register copy at the end of a step
+        // would make the wave wait for the loads right away.  Deeper pipelines measured: two steps for the flow / R0
+        // loads, four sets: the same time; two steps per hop, five sets: 164-196 VGPRs, two waves per SIMD, 10 % slower.)
         struct RowOps { float2 f; fdn_v2f r01, r23; float r4; int x1, y1; float fx, fy; GatherTapsP g; };
         auto load_ops = [&](int row, RowOps& o) __attribute__((always_inline)) {
             row = row < H ? row : H - 1;
@@ -100,11 +101,10 @@ __global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict_
             gather_R1_p(R1i, H, W, o.x1, o.y1, o.g);
         };
         int slot = 0;
-        // every hop gets HOP = 2 row steps to land (a step is about 0.9 us, a loaded HBM round trip more than that)
         auto step = [&](int t, const RowOps& cur, RowOps& mid, RowOps& far) __attribute__((always_inline)) {
             if (t < H) {
-                load_ops(t + 4, far);
-                gather_ops(t + 2, mid);
+                load_ops(t + 2, far);
+                gather_ops(t + 1, mid);
                 const float by0 = t < 5 ? (t < 2 ? 0.14f : 0.4472f) : 1.f;
                 const float by1 = t >= H - 5 ? (H - t - 1 < 2 ? 0.14f : 0.4472f) : 1.f;
                 fdn_v2f m02, m34; float m1;
@@ -118,15 +118,14 @@ __global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict_
             }
             lds_barrier_iter();
         };
-        RowOps P0, P1, P2, P3, P4;       // five sets rotate: rows t (finished), t+1, t+2 (gathered), t+3, t+4 (flow and R0 loaded)
-        load_ops(0, P0); load_ops(1, P1); load_ops(2, P2); load_ops(3, P3);
-        gather_ops(0, P0); gather_ops(1, P1);
-        for (int t = 0; t < T; t += 5) {
-            step(t, P0, P2, P4);
-            if (t + 1 < T) step(t + 1, P1, P3, P0);
-            if (t + 2 < T) step(t + 2, P2, P4, P1);
-            if (t + 3 < T) step(t + 3, P3, P0, P2);
-            if (t + 4 < T) step(t + 4, P4, P1, P3);
+        RowOps P0, P1, P2;
+        load_ops(0, P0);
+        load_ops(1, P1);
+        gather_ops(0, P0);
+        for (int t = 0; t < T; t += 3) {
+            step(t, P0, P1, P2);
+            if (t + 1 < T) step(t + 1, P1, P2, P0);
+            if (t + 2 < T) step(t + 2, P2, P0, P1);
         }
         return;
     }

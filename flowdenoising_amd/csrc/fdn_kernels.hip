@@ -53,6 +53,8 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img_b
     float* R = R_base + (size_t)blockIdx.z * 5 * HW;
     const int x0 = blockIdx.x * PE_TW, y0 = blockIdx.y * PE_TH;
 
+    // (staging the raw pixels of interior tiles in LDS -- one coalesced load per element instead of nine per blurred
+    // value -- changes nothing: 16.0 -> 16.6 ms per step; the kernel is bound by its f64 horizontal pass)
     for (int idx = threadIdx.x; idx < LW * LH; idx += 256) {
         int ty = idx / LW, tx = idx - ty * LW;
         int cy = clampi(y0 - n + ty, 0, H - 1), cx = clampi(x0 - n + tx, 0, W - 1);
@@ -722,6 +724,100 @@ __global__ __launch_bounds__(256) void k_blur_v(const float* __restrict__ in, fl
     }
     out[(size_t)blockIdx.z * HW + (size_t)y * W + x] = d;
 }
+// ---------------------------------------------------------------------------------
+// A pyramid level's image in two launches: resize(GaussianBlur(img), (w_k, h_k), INTER_LINEAR) reads only two source
+// columns and two source rows per destination pixel (cv::resize turns an exact 2 x 2 shrink into the 2 x 2 block mean),
+// so the blur is evaluated only there: 1/4 of the pixels at level 2, 1/16 at level 3.  The arithmetic of every
+// evaluated pixel is that of k_blur_h / k_blur_v / k_resize_*: same bits as blurring the whole image first.
+//   k_blur_h_sel     tmp[img][y][2 dx + c] = horizontal blur at (y, column c of dx),  all H rows
+//   k_blur_v_resize  out[img][dy][dx]      = the 2 x 2 combination of the vertical blur of those columns at dy's two rows
+// ---------------------------------------------------------------------------------
+struct ResizeSel { int area; double scale_x, scale_y; };   // area: exact 2 x 2 shrink (block mean); else INTER_LINEAR
+
+static __device__ __forceinline__ void sel_taps(int d, int n_src, double scale, int area, int& s0, int& s1, float& f)
+{
+    if (area) { s0 = 2 * d; s1 = 2 * d + 1; f = 0.f; return; }
+    f = (float)(((double)d + 0.5) * scale - 0.5);
+    float fl = floorf(f);
+    s0 = (int)fl; f -= fl;
+    if (s0 < 0) { f = 0; s0 = 0; }
+    if (s0 >= n_src - 1) { f = 0; s0 = n_src - 1; }
+    s1 = s0 + 1 < n_src ? s0 + 1 : n_src - 1;
+}
+
+__global__ __launch_bounds__(256) void k_blur_h_sel(const float* __restrict__ in, float* __restrict__ tmp, int H, int W, int dw,
+                                                    ResizeSel rs, BlurTaps bt)
+{
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (j >= 2 * dw || y >= H) return;
+    int x0, x1; float fx;
+    sel_taps(j >> 1, W, rs.scale_x, rs.area, x0, x1, fx);
+    const int x = (j & 1) ? x1 : x0;
+    const float* S = in + (size_t)blockIdx.z * H * W + (size_t)y * W;
+    const int n = bt.n, c = n / 2;
+    float s0;
+    if (n == 3) {
+        s0 = S[x] * bt.k[1] + (S[reflect101(x - 1, W)] + S[reflect101(x + 1, W)]) * bt.k[2];
+    } else if (n == 5) {
+        s0 = S[x] * bt.k[2] + (S[reflect101(x - 1, W)] + S[reflect101(x + 1, W)]) * bt.k[3]
+             + (S[reflect101(x - 2, W)] + S[reflect101(x + 2, W)]) * bt.k[4];
+    } else {
+        s0 = bt.k[0] * S[reflect101(x - c, W)];
+        for (int q = 1; q < n; q++) s0 = s0 + bt.k[q] * S[reflect101(x - c + q, W)];
+    }
+    tmp[((size_t)blockIdx.z * H + y) * (2 * dw) + j] = s0;
+}
+
+__global__ __launch_bounds__(256) void k_blur_v_resize(const float* __restrict__ tmp, float* __restrict__ out, int H, int dh, int dw,
+                                                       int W, ResizeSel rs, BlurTaps bt)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    int y0, y1, xa, xb; float fy, fx;
+    sel_taps(dy, H, rs.scale_y, rs.area, y0, y1, fy);
+    sel_taps(dx, W, rs.scale_x, rs.area, xa, xb, fx);        // only the fraction is needed here
+    const float* T = tmp + (size_t)blockIdx.z * H * (2 * dw) + 2 * dx;
+    const int pitch = 2 * dw, c = bt.n / 2;
+    float v[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int y = r ? y1 : y0;
+        const float2 t0 = *(const float2*)(T + (size_t)y * pitch);
+        float da = bt.k[c] * t0.x, db = bt.k[c] * t0.y;
+        for (int q = 1; q <= c; q++) {
+            const float2 sp = *(const float2*)(T + (size_t)reflect101(y + q, H) * pitch);
+            const float2 sm = *(const float2*)(T + (size_t)reflect101(y - q, H) * pitch);
+            da = da + bt.k[c + q] * (sp.x + sm.x);
+            db = db + bt.k[c + q] * (sp.y + sm.y);
+        }
+        v[r][0] = da; v[r][1] = db;
+    }
+    float res;
+    if (rs.area) {     // k_resize_area_int: f32 block sum in row-major order, times 1/4
+        float sum = 0;
+        sum = sum + v[0][0]; sum = sum + v[0][1]; sum = sum + v[1][0]; sum = sum + v[1][1];
+        res = sum * (1.f / 4.f);
+    } else {           // k_resize_linear
+        const float a1 = fx, a0 = 1.f - fx, b1 = fy, b0 = 1.f - fy;
+        const float r0 = v[0][0] * a0 + v[0][1] * a1;
+        const float r1 = v[1][0] * a0 + v[1][1] * a1;
+        res = r0 * b0 + r1 * b1;
+    }
+    out[((size_t)blockIdx.z * dh + dy) * dw + dx] = res;
+}
+
+// small = resize(GaussianBlur(in, taps bt), (dw, dh), INTER_LINEAR) for nimg images; tmp: nimg * H * 2 dw floats
+void launch_blur_resize(const float* in, float* tmp, float* small, int nimg, int H, int W, int dh, int dw, const BlurTaps& bt, hipStream_t st)
+{
+    if (nimg <= 0) return;
+    const double scale_x = (double)W / dw, scale_y = (double)H / dh;
+    const int isx = (int)scale_x, isy = (int)scale_y;
+    const bool integer = fabs(scale_x - isx) < 2.220446049250313e-16 && fabs(scale_y - isy) < 2.220446049250313e-16;
+    ResizeSel rs{integer && isx == 2 && isy == 2 ? 1 : 0, scale_x, scale_y};
+    hipLaunchKernelGGL(k_blur_h_sel, dim3((2 * dw + 63) / 64, (H + 3) / 4, nimg), dim3(256), 0, st, in, tmp, H, W, dw, rs, bt);
+    hipLaunchKernelGGL(k_blur_v_resize, dim3((dw + 63) / 64, (dh + 3) / 4, nimg), dim3(256), 0, st, tmp, small, H, dh, dw, W, rs, bt);
+}
+
 void launch_gaussian_blur(const float* in, float* tmp, float* out, int nimg, int H, int W, const BlurTaps& bt, hipStream_t st)
 {
     if (nimg <= 0) return;

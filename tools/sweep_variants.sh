@@ -8,6 +8,6 @@ for f in build_variants/lib_*.so; do
   cp $f flowdenoising_amd/libflowdn.so
   if [ $first = 1 ]; then timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > gpurun_out/sweep_parity.log 2>&1 && tail -1 gpurun_out/sweep_parity.log; first=0; fi
   echo "== $f" | tee -a gpurun_out/sweep.log
-  timeout -k 10 120 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline'].get('avg_launch_ms'), d.get('kernel_ms_per_step'))" | tee -a gpurun_out/sweep.log
+  timeout -k 10 200 python bench.py $BENCH_ARGS --steps 2 --warmup 1 --no-cpu-baseline --no-check 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline'].get('avg_launch_ms'), d.get('kernel_ms_per_step'))" | tee -a gpurun_out/sweep.log
 done
 cp /tmp/lib_default.so flowdenoising_amd/libflowdn.so
