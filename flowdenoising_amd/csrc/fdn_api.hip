@@ -539,7 +539,7 @@ static int chain_step_iter(fdn_ctx* h, const std::vector<PyrLevel>& lv, const fl
             ScopedTimer t(h, FDN_TIMER_ITER);
             if (launch_farneback_iter(Rk, stack, fin, last && !keep ? nullptr : fout, last ? acc : nullptr, pb, lv[k].h, lv[k].w,
                                       winsize, weight, h->stream, ch, cw))
-                return fail("k_farneback_iter could not be launched (winsize %d needs %zu bytes of LDS)", winsize, iter_lds_bytes(winsize / 2));
+                return fail("k_farneback_iter could not be launched (winsize %d needs %zu bytes of LDS)", winsize, iter_lds_bytes(winsize / 2, true));
             fin = fout; ch = cw = 0;
         }
         ch = lv[k].h; cw = lv[k].w;   // the next (finer) level upsamples this one's result

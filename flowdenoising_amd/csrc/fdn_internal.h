@@ -90,7 +90,7 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
 // then be nullptr).  flow_in nullptr = zero flow; coarse_h/w > 0: flow_in is the next coarser level's flow of that size.
 // Returns 0, or -1 when the launch could not be configured.
 bool iter_supported(int winsize, int H, int W);
-size_t iter_lds_bytes(int mh);
+size_t iter_lds_bytes(int mh, bool acc);
 int launch_farneback_iter(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
                           PairBatch pb, int H, int W, int winsize, double weight, hipStream_t st,
                           int coarse_h = 0, int coarse_w = 0);

@@ -10,13 +10,16 @@
 // HBM, and what an iteration costs in HBM is its operands: R0 20 + R1 20 + flow in 8 + flow out 8 bytes per
 // pixel (the staged kernels move 308 per chain step, three of these launches 180).
 //
-// Workgroup = 128 threads = one 64-column band of one (target, neighbour) pair, marching down the rows:
+// Workgroup = 128 threads (192 on the warping launch) = one 64-column band of one (target, neighbour) pair, marching
+// down the rows:
 //   wave 0 (producer)  row t         : M row from flow_in, R0 and the bilinear gather of R1 -> LDS ring slot t % RS
 //   wave 1 (consumer)  row t - MH - 1: OpenCV's vertical running sum vsum += f32(M[y+MH] - M[y-MH-1]) (carried in
 //                                      registers from row 0: the f32-fed recurrence is what makes results bit-faithful,
 //                                      DESIGN.md 3.2), horizontal window across lanes by doubling through LDS rows,
-//                                      2 x 2 solve, store; on the last iteration of level 0 the 1/32-px remap of the
-//                                      neighbour and acc = f32(f64(acc) + f64(v) w) (seq:106-107)
+//                                      2 x 2 solve, store
+//   wave 2 (warper)    row t - MH - 2: last iteration of level 0 only: the 1/32-px remap of the neighbour at p + flow
+//                                      and acc = f32(f64(acc) + f64(v) w) (seq:106-107); the flow comes from the
+//                                      consumer through two LDS slots
 //   one s_barrier per row step; the ring holds rows t - 2 MH - 1 .. t (RS = 2 MH + 2 rows x 1280 B): the slot the
 //   producer writes in step t held row t - 2 MH - 2, the consumer's trailing row of this step -- which it has read
 //   one step ahead, into registers.
@@ -35,7 +38,7 @@ static __device__ __forceinline__ void lds_barrier_iter()
 // image's size, 2: flow_in is the next coarser level's (fs.h x fs.w) result, resized INTER_LINEAR and doubled on the fly
 // (calc()'s upsampling).  ACC: also warp the neighbour with the new flow and accumulate.
 template <int MHT, int FIN, bool ACC>
-__global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict__ Rstack, const float* __restrict__ stack,
+__global__ __launch_bounds__(ACC ? 192 : 128) void k_farneback_iter(const float* __restrict__ Rstack, const float* __restrict__ stack,
                                                         const float* __restrict__ flow_in_base, float* __restrict__ flow_out_base,
                                                         float* __restrict__ acc_base, PairBatch pb, int H, int W, int mh_rt,
                                                         double scale, double weight, int nbands, FlowSource fs)
@@ -51,6 +54,8 @@ __global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict_
     // values that only reach lanes whose results are never used (the band's halo lanes)
     double* xch = (double*)(lds + (size_t)RS * 320);
     const int XR = 5 * 64 + 2 * MH + 2;
+    // warping launches: the flow of a row goes from the consumer to the third wave through two slots of 64 float2
+    float2* fho = (float2*)(xch + 2 * XR);
 
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict_
     const int x = xb + lane;
     const int xc = clampi(x, 0, W - 1);       // lanes outside the image replicate the border column (BORDER_REPLICATE of vsum)
     const size_t HW = (size_t)H * W;
-    const int T = H + MH + 1;                 // row steps = barriers both waves execute
+    const int T = H + MH + 1 + (ACC ? 1 : 0); // row steps = barriers every wave executes
 
     if (role == 0) {
         // ===== producer ==================================================================================
@@ -130,11 +135,31 @@ __global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict_
         return;
     }
 
-    // ===== consumer ======================================================================================
     const bool owner = lane >= MH && lane < 64 - MH && x < W;
     const float* img1 = ACC ? uniform_ptr(stack + (size_t)(pb.t0 + b + pb.d) * HW) : nullptr;
     float2* flow_out = flow_out_base ? uniform_ptr((float2*)flow_out_base + (size_t)b * HW) : nullptr;
     float* acc = ACC ? uniform_ptr(acc_base + (size_t)b * HW) : nullptr;
+
+    if (ACC && role == 2) {
+        // ===== warper (warping launches only): row t - MH - 2, one step behind the consumer ==============
+        // acc = f32(f64(acc) + f64(remap(neighbour, p + flow)) w) (seq:106-107).  The remap's four taps sit at p + flow: a
+        // dependent global gather whose latency would otherwise sit in the consumer's step (12.0 against 9.2 ms per launch).
+        for (int t = 0; t < T; t++) {
+            const int y = t - MH - 2;
+            if (y >= 0 && y < H) {
+                const float2 f = fho[(y & 1) * 64 + lane];
+                const unsigned o = (unsigned)y * (unsigned)W + (unsigned)xc;
+                const float acc_old = ld_off<float>(acc, o * 4u);
+                const float warped = remap_sample(img1, H, W, xc, y, f);
+                const float acc_new = (float)((double)acc_old + (double)warped * weight);
+                if (owner) st_off(acc, o * 4u, acc_new);
+            }
+            lds_barrier_iter();
+        }
+        return;
+    }
+
+    // ===== consumer ======================================================================================
     auto ring_row = [&](int r, float m[5]) __attribute__((always_inline)) {       // channels in OpenCV's order m0..m4
         const float* row = ring + (size_t)(r % RS) * 320;
         const fdn_v2f p = *(const fdn_v2f*)(row + 2 * lane), q = *(const fdn_v2f*)(row + 128 + 2 * lane);
@@ -154,11 +179,9 @@ __global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict_
                 for (int c = 0; c < 5; c++) vs[c] += (double)m[c];
             }
             ring_row(0, trail);          // row 0's trailing row is row 0 (clamped)
-        } else if (t > MH) {
+        } else if (t > MH && t - MH - 1 < H) {
             const int y = t - MH - 1;
             const unsigned o = (unsigned)y * (unsigned)W + (unsigned)xc;
-            float acc_old = 0.f;
-            if (ACC) acc_old = ld_off<float>(acc, o * 4u);      // does not depend on this step's flow: load it first
             float lead[5];
             ring_row(y + MH < H - 1 ? y + MH : H - 1, lead);
 #pragma unroll
@@ -202,16 +225,8 @@ __global__ __launch_bounds__(128) void k_farneback_iter(const float* __restrict_
                 __builtin_amdgcn_wave_barrier();
             }
             const float2 f = solve_flow(a, scale);
-            if (ACC) {
-                const float warped = remap_sample(img1, H, W, xc, y, f);
-                const float acc_new = (float)((double)acc_old + (double)warped * weight);
-                if (owner) {
-                    if (flow_out) st_off(flow_out, o * 8u, f);
-                    st_off(acc, o * 4u, acc_new);
-                }
-            } else if (owner) {
-                st_off(flow_out, o * 8u, f);
-            }
+            if (ACC) fho[(y & 1) * 64 + lane] = f;         // to the warper; this slot was last read two steps ago
+            if (owner && flow_out) st_off(flow_out, o * 8u, f);
         }
         lds_barrier_iter();
     }
@@ -224,7 +239,10 @@ bool iter_supported(int winsize, int H, int W)
     return mh >= 1 && mh <= 24 && H >= 2 && W >= 2 && H < (1 << 24) && W < (1 << 24) && (size_t)H * W < ((size_t)1 << 29);
 }
 
-size_t iter_lds_bytes(int mh) { return (size_t)(2 * mh + 2) * 320 * sizeof(float) + (size_t)2 * (5 * 64 + 2 * mh + 2) * sizeof(double); }
+size_t iter_lds_bytes(int mh, bool acc)
+{
+    return (size_t)(2 * mh + 2) * 320 * sizeof(float) + (size_t)2 * (5 * 64 + 2 * mh + 2) * sizeof(double) + (acc ? 2 * 64 * sizeof(float2) : 0);
+}
 
 template <int MHT>
 static int launch_iter_t(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc, PairBatch pb,
@@ -233,11 +251,11 @@ static int launch_iter_t(const float* Rstack, const float* stack, const float* f
     const int BW = 64 - 2 * mh;
     const int nbands = (W + BW - 1) / BW;
     dim3 grid((unsigned)((long)nbands * pb.npairs));
-    const size_t lds = iter_lds_bytes(mh);
+    const size_t lds = iter_lds_bytes(mh, acc != nullptr);
     const int fin = !flow_in ? 0 : fs.h > 0 ? 2 : 1;
     auto launch = [&](auto kern) -> int {
         if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-        hipLaunchKernelGGL(kern, grid, dim3(128), lds, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, nbands, fs);
+        hipLaunchKernelGGL(kern, grid, dim3(acc ? 192 : 128), lds, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, nbands, fs);
         return 0;
     };
     if (acc) {
