@@ -30,7 +30,8 @@ class SweepParams(ctypes.Structure):
 # every symbol include/flowdn.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "fdn_create", "fdn_destroy", "fdn_last_error", "fdn_set_stream", "fdn_reset_stream", "fdn_synchronize",
-    "fdn_set_workspace_limit", "fdn_workspace_bytes", "fdn_set_option", "fdn_malloc", "fdn_free", "fdn_memcpy_h2d", "fdn_memcpy_d2h",
+    "fdn_set_workspace_limit", "fdn_workspace_bytes", "fdn_mem_info", "fdn_set_option", "fdn_malloc", "fdn_free", "fdn_memcpy_h2d", "fdn_memcpy_d2h",
+    "fdn_memcpy2d_h2d", "fdn_memcpy2d_d2h", "fdn_host_register", "fdn_host_unregister",
     "fdn_memset_f32", "fdn_gaussian_kernel", "fdn_farneback", "fdn_farneback_strided", "fdn_farneback_dev",
     "fdn_warp", "fdn_warp_strided", "fdn_warp_dev",
     "fdn_filter_axis_dev", "fdn_filter_axis", "fdn_filter_3d_dev", "fdn_filter_3d",
@@ -155,6 +156,12 @@ class Handle:
         check(self._lib.fdn_workspace_bytes(self._h, ctypes.byref(n)))
         return n.value
 
+    def mem_info(self):
+        """(free, total) bytes of device memory."""
+        f, t = ctypes.c_size_t(), ctypes.c_size_t()
+        check(self._lib.fdn_mem_info(self._h, ctypes.byref(f), ctypes.byref(t)))
+        return f.value, t.value
+
     def set_option(self, name, value):
         """fdn_set_option: "strict_order", "path", "fused_occ", "lds_pad" (see include/flowdn.h)."""
         check(self._lib.fdn_set_option(self._h, ctypes.c_char_p(name.encode()), ctypes.c_long(int(value))))
@@ -174,6 +181,21 @@ class Handle:
     def d2h(self, arr, dptr):
         assert arr.flags["C_CONTIGUOUS"]
         check(self._lib.fdn_memcpy_d2h(self._h, _ptr(arr), ctypes.c_void_p(dptr), ctypes.c_size_t(arr.nbytes)))
+
+    def h2d_2d(self, dptr, dpitch, host_ptr, spitch, width_bytes, height):
+        check(self._lib.fdn_memcpy2d_h2d(self._h, ctypes.c_void_p(dptr), ctypes.c_size_t(dpitch), ctypes.c_void_p(host_ptr),
+                                         ctypes.c_size_t(spitch), ctypes.c_size_t(width_bytes), ctypes.c_size_t(height)))
+
+    def d2h_2d(self, host_ptr, dpitch, dptr, spitch, width_bytes, height):
+        check(self._lib.fdn_memcpy2d_d2h(self._h, ctypes.c_void_p(host_ptr), ctypes.c_size_t(dpitch), ctypes.c_void_p(dptr),
+                                         ctypes.c_size_t(spitch), ctypes.c_size_t(width_bytes), ctypes.c_size_t(height)))
+
+    def host_register(self, arr):
+        """Page-lock a numpy array's memory; returns True if it worked (a read-only mapping, say, cannot be locked)."""
+        return self._lib.fdn_host_register(self._h, ctypes.c_void_p(arr.ctypes.data), ctypes.c_size_t(arr.nbytes)) == 0
+
+    def host_unregister(self, arr):
+        self._lib.fdn_host_unregister(self._h, ctypes.c_void_p(arr.ctypes.data))
 
     def memset_f32(self, dptr, value, count):
         check(self._lib.fdn_memset_f32(self._h, ctypes.c_void_p(dptr), ctypes.c_float(float(value)), ctypes.c_size_t(int(count))))

@@ -909,6 +909,15 @@ FDN_API int fdn_set_workspace_limit(fdn_handle h, size_t bytes)
     h->ws_limit = bytes;
     return 0;
 }
+FDN_API int fdn_mem_info(fdn_handle h, size_t* free_out, size_t* total_out)
+{
+    FDN_ENTER(h);
+    size_t fre = 0, tot = 0;
+    FDN_HIP(hipMemGetInfo(&fre, &tot));
+    if (free_out) *free_out = fre;
+    if (total_out) *total_out = tot;
+    return 0;
+}
 FDN_API int fdn_workspace_bytes(fdn_handle h, size_t* bytes_out)
 {
     FDN_ENTER(h);
@@ -956,6 +965,42 @@ FDN_API int fdn_memcpy_d2h(fdn_handle h, void* dst, const void* src, size_t byte
     ScopedTimer t(h, FDN_TIMER_TRANSFER);
     FDN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
     FDN_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+// strided host <-> device copies (a slab of a host volume that is not contiguous: volume[:, y0:y1, :] or volume[:, :, x0:x1])
+FDN_API int fdn_memcpy2d_h2d(fdn_handle h, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t height)
+{
+    FDN_ENTER(h);
+    if (!dst || !src) return fail("NULL pointer");
+    if (!width_bytes || !height) return 0;
+    ScopedTimer t(h, FDN_TIMER_TRANSFER);
+    FDN_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, hipMemcpyHostToDevice, h->stream));
+    FDN_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+FDN_API int fdn_memcpy2d_d2h(fdn_handle h, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t height)
+{
+    FDN_ENTER(h);
+    if (!dst || !src) return fail("NULL pointer");
+    if (!width_bytes || !height) return 0;
+    ScopedTimer t(h, FDN_TIMER_TRANSFER);
+    FDN_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, hipMemcpyDeviceToHost, h->stream));
+    FDN_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+// page-lock / release a caller's host buffer so that copies from and to it run as DMA at PCIe speed
+FDN_API int fdn_host_register(fdn_handle h, void* ptr, size_t bytes)
+{
+    FDN_ENTER(h);
+    if (!ptr || !bytes) return fail("NULL pointer");
+    FDN_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return 0;
+}
+FDN_API int fdn_host_unregister(fdn_handle h, void* ptr)
+{
+    FDN_ENTER(h);
+    if (!ptr) return fail("NULL pointer");
+    FDN_HIP(hipHostUnregister(ptr));
     return 0;
 }
 FDN_API int fdn_memset_f32(fdn_handle h, float* dst, float value, size_t count)

@@ -42,6 +42,8 @@ def filter_streamed(vol, kernels, l, w, chunk_slices=None, use_of=True, border_m
         raise ValueError(f"expected a (Z, Y, X) volume, got shape {src.shape}")
     if src.dtype != np.float32:
         src = src.astype(np.float32)
+    if not src.flags["C_CONTIGUOUS"]:
+        src = np.ascontiguousarray(src)
     if mean is None:
         mean = _lib.mean_host(src)                      # seq:420
     wrap = border_mode == _lib.BORDER_WRAP
@@ -50,8 +52,7 @@ def filter_streamed(vol, kernels, l, w, chunk_slices=None, use_of=True, border_m
     h = handle(device)
     free = None
     if chunk_slices is None:
-        import torch                                     # only to ask for the free device memory
-        free = torch.cuda.mem_get_info(device)[0] if torch.cuda.is_available() else 64 << 30
+        free = h.mem_info()[0]
         if src.size * (_BYTES_PER_TARGET_PIXEL + 8) < 0.7 * free:      # everything fits: the resident path
             h2 = handle(device)
             d_in = h2.malloc(src.nbytes)
@@ -72,11 +73,23 @@ def filter_streamed(vol, kernels, l, w, chunk_slices=None, use_of=True, border_m
     tls = threading.local()
     made = []
 
-    def worker_handle():              # one handle (stream, workspaces) per worker thread
+    def worker_handle():              # one handle (stream, workspaces) and one set of device buffers per worker thread
         if not hasattr(tls, "h"):
             tls.h = _lib.Handle(device)
-            made.append(tls.h)
-        return tls.h
+            tls.bufs = {}
+            made.append((tls.h, tls.bufs))
+        h, bufs = tls.h, tls.bufs
+
+        def dev(name, nbytes):        # grows, never shrinks within the call
+            p, cap = bufs.get(name, (0, 0))
+            if cap < nbytes:
+                if p:
+                    h.free(p)
+                p = h.malloc(nbytes)
+                bufs[name] = (p, nbytes)
+            return p
+        return h, dev
+    worker_handle.device = device
 
     pool = ThreadPoolExecutor(max_workers=max(1, int(workers)))
     try:
@@ -84,84 +97,95 @@ def filter_streamed(vol, kernels, l, w, chunk_slices=None, use_of=True, border_m
                       pool, worker_handle)
     finally:
         pool.shutdown(wait=True)
-        for hh in made:
+        for hh, bb in made:
+            for p, _ in bb.values():
+                hh.free(p)
             hh.close()
-    return cur if cur is not src else src.copy()
+    return cur.copy() if cur is src else cur
 
 
 def _passes(src, kernels, chunk_slices, free, mean, wrap, params, pool, worker_handle):
+    """Z, Y, X passes over a host volume.  A chunk's slices travel as they lie in the host array -- contiguous for Z,
+    strided 2-D copies for Y (Z rows of cnt * X floats) and X (Z * Y rows of cnt floats), fdn_memcpy2d_* -- between
+    page-locked host arrays (the input and two ping-pong result arrays are registered once) and per-worker device
+    buffers that live for the whole call; the re-orientation happens on the GPU (fdn_permute_dev)."""
     cur = src
-    for axis in (0, 1, 2):
-        k = kernels[axis]
-        if k is None:
-            continue
-        k = np.ascontiguousarray(k, dtype=np.float64)
-        r = k.size // 2
-        n = cur.shape[axis]
-        other = [a for a in range(3) if a != axis]
-        H, W = cur.shape[other[0]], cur.shape[other[1]]   # the pass's images (seq:255, seq:333)
-        HW = H * W
-        out = np.empty(cur.shape, dtype=np.float32)
-        if chunk_slices is None:
-            step = auto_chunk(cur.shape, axis, r, free)
-        else:
-            step = max(1, int(chunk_slices))
-        def chunk_job(s0, s1, cur=cur, out=out, axis=axis, k=k, r=r, n=n, H=H, W=W, HW=HW):
-            h = worker_handle()
-            S = s1 - s0
-            # source slices of stack positions 0 .. S+2r-1 as runs of consecutive slices (host order)
-            if wrap:
-                idx = np.arange(s0 - r, s1 + r) % n
-                cuts = [0] + [i + 1 for i in range(idx.size - 1) if idx[i + 1] != idx[i] + 1] + [idx.size]
-                runs = [(cuts[j], int(idx[cuts[j]]), cuts[j + 1] - cuts[j]) for j in range(len(cuts) - 1)]
+    bufs = [None, None]                # host ping-pong results
+    locked = []
+    main = _lib.Handle(worker_handle.device)
+    try:
+        if src.flags["WRITEABLE"] and main.host_register(src):      # a read-only memory map cannot be page-locked: copied pageable
+            locked.append(src)
+        npass = 0
+        for axis in (0, 1, 2):
+            k = kernels[axis]
+            if k is None:
+                continue
+            k = np.ascontiguousarray(k, dtype=np.float64)
+            r = k.size // 2
+            Z, Y, X = cur.shape
+            n = cur.shape[axis]
+            other = [a for a in range(3) if a != axis]
+            H, W = cur.shape[other[0]], cur.shape[other[1]]   # the pass's images (seq:255, seq:333)
+            HW = H * W
+            if bufs[npass & 1] is None:
+                bufs[npass & 1] = np.empty(cur.shape, dtype=np.float32)
+                if main.host_register(bufs[npass & 1]):
+                    locked.append(bufs[npass & 1])
+            out = bufs[npass & 1]
+            npass += 1
+            if chunk_slices is None:
+                step = auto_chunk(cur.shape, axis, r, free)
             else:
-                lo, hi = max(0, s0 - r), min(n, s1 + r)
-                runs = [(lo - (s0 - r), lo, hi - lo)]
-            d_stack = h.malloc((S + 2 * r) * HW * 4)
-            d_out = d_blk = None
-            try:
-                d_out = h.malloc(S * HW * 4)
-                d_blk = h.malloc((S + 2 * r) * HW * 4) if axis else None
+                step = max(1, int(chunk_slices))
+
+            def chunk_job(s0, s1, cur=cur, out=out, axis=axis, k=k, r=r, n=n, H=H, W=W, HW=HW, Z=Z, Y=Y, X=X, step=step):
+                h, dev = worker_handle()
+                S = s1 - s0
+                # source slices of stack positions 0 .. S+2r-1 as runs of consecutive slices (host order)
+                if wrap:
+                    idx = np.arange(s0 - r, s1 + r) % n
+                    cuts = [0] + [i + 1 for i in range(idx.size - 1) if idx[i + 1] != idx[i] + 1] + [idx.size]
+                    runs = [(cuts[j], int(idx[cuts[j]]), cuts[j + 1] - cuts[j]) for j in range(len(cuts) - 1)]
+                else:
+                    lo, hi = max(0, s0 - r), min(n, s1 + r)
+                    runs = [(lo - (s0 - r), lo, hi - lo)]
+                d_stack = dev("stack", (step + 2 * r) * HW * 4)
+                d_out = dev("out", step * HW * 4)
+                d_blk = dev("blk", (step + 2 * r) * HW * 4) if axis else None
                 if not wrap:                              # seq:88-89: slices beyond the volume ends hold the mean
                     p0, _, cnt = runs[0]
                     if p0:
                         h.memset_f32(d_stack, mean, p0 * HW)
                     if p0 + cnt < S + 2 * r:
                         h.memset_f32(d_stack + (p0 + cnt) * HW * 4, mean, (S + 2 * r - p0 - cnt) * HW)
+                base = cur.ctypes.data
                 for p0, g0, cnt in runs:                  # upload in the volume's own layout, re-orient on the GPU
-                    sl = [slice(None)] * 3
-                    sl[axis] = slice(g0, g0 + cnt)
-                    blk = np.ascontiguousarray(cur[tuple(sl)])
                     dst = d_stack + p0 * HW * 4
                     if axis == 0:
-                        h.h2d(dst, blk)
-                    else:
-                        h.h2d(d_blk, blk)
-                        if axis == 1:                     # (Z, cnt, X) -> (cnt, Z, X)
-                            h.permute_dev(d_blk, dst, (cnt, H, W), (W, cnt * W, 1))
-                        else:                             # (Z, Y, cnt) -> (cnt, Z, Y)
-                            h.permute_dev(d_blk, dst, (cnt, H, W), (1, W * cnt, cnt))
+                        h.h2d_2d(dst, cnt * HW * 4, base + g0 * HW * 4, cnt * HW * 4, cnt * HW * 4, 1)
+                    elif axis == 1:                       # volume[:, g0:g0+cnt, :]: Z rows of cnt * X floats -> (cnt, Z, X)
+                        h.h2d_2d(d_blk, cnt * X * 4, base + g0 * X * 4, Y * X * 4, cnt * X * 4, Z)
+                        h.permute_dev(d_blk, dst, (cnt, H, W), (W, cnt * W, 1))
+                    else:                                 # volume[:, :, g0:g0+cnt]: Z * Y rows of cnt floats -> (cnt, Z, Y)
+                        h.h2d_2d(d_blk, cnt * 4, base + g0 * 4, X * 4, cnt * 4, Z * Y)
+                        h.permute_dev(d_blk, dst, (cnt, H, W), (1, W * cnt, cnt))
                 h.sweep_stack_dev(d_stack, d_out, S, H, W, k, params)
-                sl = [slice(None)] * 3
-                sl[axis] = slice(s0, s1)
+                obase = out.ctypes.data
                 if axis == 0:
-                    res = np.empty((S, H, W), dtype=np.float32)
-                    h.d2h(res, d_out)
-                elif axis == 1:                           # (S, Z, X) -> (Z, S, X)
+                    h.d2h_2d(obase + s0 * HW * 4, S * HW * 4, d_out, S * HW * 4, S * HW * 4, 1)
+                elif axis == 1:                           # (S, Z, X) -> (Z, S, X) -> out[:, s0:s1, :]
                     h.permute_dev(d_out, d_blk, (H, S, W), (W, H * W, 1))
-                    res = np.empty((H, S, W), dtype=np.float32)
-                    h.d2h(res, d_blk)
-                else:                                     # (S, Z, Y) -> (Z, Y, S)
+                    h.d2h_2d(obase + s0 * X * 4, Y * X * 4, d_blk, S * X * 4, S * X * 4, Z)
+                else:                                     # (S, Z, Y) -> (Z, Y, S) -> out[:, :, s0:s1]
                     h.permute_dev(d_out, d_blk, (H, W, S), (W, 1, H * W))
-                    res = np.empty((H, W, S), dtype=np.float32)
-                    h.d2h(res, d_blk)
-                out[tuple(sl)] = res
-            finally:
-                for d in (d_blk, d_out, d_stack):
-                    if d:
-                        h.free(d)
-        list(pool.map(lambda se: chunk_job(*se), [(s0, min(n, s0 + step)) for s0 in range(0, n, step)]))
-        cur = out
+                    h.d2h_2d(obase + s0 * 4, X * 4, d_blk, S * 4, S * 4, Z * Y)
+            list(pool.map(lambda se: chunk_job(*se), [(s0, min(n, s0 + step)) for s0 in range(0, n, step)]))
+            cur = out
+    finally:
+        for a in locked:
+            main.host_unregister(a)
+        main.close()
     return cur
 
 

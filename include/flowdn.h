@@ -72,6 +72,8 @@ int fdn_synchronize(fdn_handle h);
  * Setting it releases what the handle holds.  fdn_workspace_bytes reports what it holds now. */
 int fdn_set_workspace_limit(fdn_handle h, size_t bytes);
 int fdn_workspace_bytes(fdn_handle h, size_t* bytes_out);
+/* free and total device memory (hipMemGetInfo): what the out-of-core mode sizes its chunks by */
+int fdn_mem_info(fdn_handle h, size_t* free_out, size_t* total_out);
 
 /* Switches of a live handle (tests and experiments; fdn_create reads the same from the environment:
  * FDN_STRICT_ORDER, FDN_PATH / FDN_FORCE_STAGED, FDN_FUSED_OCC, FDN_LDS_PAD).  Every path gives the same
@@ -91,6 +93,15 @@ int fdn_free(fdn_handle h, void* dptr);
 int fdn_memcpy_h2d(fdn_handle h, void* dst_dev, const void* src_host, size_t bytes);
 int fdn_memcpy_d2h(fdn_handle h, void* dst_host, const void* src_dev, size_t bytes);
 int fdn_memset_f32(fdn_handle h, float* dst_dev, float value, size_t count);
+/* strided copies: `height` rows of `width_bytes`, row r at base + r * pitch (a slab volume[:, y0:y1, :] or
+ * volume[:, :, x0:x1] of a host volume moves without a host-side gather; the out-of-core mode uses them) */
+int fdn_memcpy2d_h2d(fdn_handle h, void* dst_dev, size_t dst_pitch, const void* src_host, size_t src_pitch,
+                     size_t width_bytes, size_t height);
+int fdn_memcpy2d_d2h(fdn_handle h, void* dst_host, size_t dst_pitch, const void* src_dev, size_t src_pitch,
+                     size_t width_bytes, size_t height);
+/* page-lock / release a host buffer of the caller (hipHostRegister): copies from and to it then run at PCIe speed */
+int fdn_host_register(fdn_handle h, void* ptr, size_t bytes);
+int fdn_host_unregister(fdn_handle h, void* ptr);
 
 /* ---- a-1  get_gaussian_kernel(sigma)  (seq:30-41, par:34-45) ---------------------- */
 /* Writes K = 2*int(4*sigma+0.5)+1 float64 taps; returns K, or -K if cap < K. Host only. */
