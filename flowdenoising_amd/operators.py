@@ -111,11 +111,22 @@ def filter_3d_own_mean(vol, kernel, params, device=0):
     try:
         d_out = h.malloc(vol.nbytes)
         try:
-            h.h2d(d_in, vol)
+            out = np.empty_like(vol)
+            big = vol.nbytes >= (8 << 20)
+            pin_in = big and vol.flags["WRITEABLE"] and h.host_register(vol)      # DMA at PCIe speed instead of staged copies
+            try:
+                h.h2d(d_in, vol)
+            finally:
+                if pin_in:
+                    h.host_unregister(vol)
             mean = h.mean_dev(d_in, vol.size)
             h.filter_3d_dev(d_in, d_out, vol.shape, kernel, mean, params)
-            out = np.empty_like(vol)
-            h.d2h(out, d_out)
+            pin_out = big and h.host_register(out)
+            try:
+                h.d2h(out, d_out)
+            finally:
+                if pin_out:
+                    h.host_unregister(out)
             return out
         finally:
             h.free(d_out)

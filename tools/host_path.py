@@ -25,3 +25,9 @@ for it in range(3):
     print(f"run {it}: resident {t_dev*1e3:.0f} ms, host pointers {t_host*1e3:.0f} ms (+{(t_host-t_dev)*1e3:.0f} ms; transfer timer {tm['transfer'][0]:.0f} ms "
           f"= {2*host.nbytes/tm['transfer'][0]/1e6:.1f} GB/s); {host.size/t_host/1e6:.0f} Mvox/s end to end", flush=True)
 assert np.array_equal(res, out.cpu().numpy())
+import flowdenoising_amd as fd
+for it in range(2):
+    t0 = time.perf_counter()
+    res2 = fd.OF_filter(host, [k, k, k], 0, 5)
+    print(f"OF_filter (numpy in, fresh numpy out, mean on the GPU): {(time.perf_counter()-t0)*1e3:.0f} ms = {host.size/(time.perf_counter()-t0)/1e6:.0f} Mvox/s", flush=True)
+assert np.array_equal(res2, res)
