@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libflowdn.so")
 USE_INITIAL_FLOW = 4
 BORDER_MEAN_PAD = 0
 BORDER_WRAP = 1
-TIMER_NAMES = ("polyexp", "update_matrices", "update_flow", "warp", "permute", "transfer", "fused", "iter")
+TIMER_NAMES = ("polyexp", "update_matrices", "update_flow", "warp", "permute", "transfer", "fused", "iter", "collective")
 
 
 class FlowdnError(RuntimeError):
@@ -36,7 +36,7 @@ EXPORTS = [
     "fdn_warp", "fdn_warp_strided", "fdn_warp_dev",
     "fdn_filter_axis_dev", "fdn_filter_axis", "fdn_filter_3d_dev", "fdn_filter_3d",
     "fdn_mean_host", "fdn_mean_dev", "fdn_np_chunk_sums_dev", "fdn_sum_dev", "fdn_sweep_stack_dev", "fdn_permute_dev",
-    "fdn_enable_timers", "fdn_get_timers", "fdn_version",
+    "fdn_enable_timers", "fdn_get_timers", "fdn_add_timer", "fdn_version",
 ]
 
 _lib = None
@@ -209,6 +209,10 @@ class Handle:
         cnt = (ctypes.c_longlong * len(TIMER_NAMES))()
         check(self._lib.fdn_get_timers(self._h, ms, cnt, ctypes.c_int(int(reset))))
         return {n: (ms[i], cnt[i]) for i, n in enumerate(TIMER_NAMES)}
+
+    def add_timer(self, name, ms, count=1):
+        """fdn_add_timer: time measured by the host layer (the multi-GPU exchanges) into the handle's timer table."""
+        check(self._lib.fdn_add_timer(self._h, ctypes.c_int(TIMER_NAMES.index(name)), ctypes.c_double(float(ms)), ctypes.c_longlong(int(count))))
 
     # -- pair operators ------------------------------------------------------------
     @staticmethod

@@ -1358,6 +1358,14 @@ FDN_API int fdn_enable_timers(fdn_handle h, int on)
     h->timers = on != 0;
     return 0;
 }
+FDN_API int fdn_add_timer(fdn_handle h, int which, double ms, long long count)
+{
+    FDN_ENTER(h);
+    if (which < 0 || which >= FDN_TIMER_COUNT) return fail("timer category %d out of range", which);
+    h->tms[which] += ms;
+    h->tcount[which] += count;
+    return 0;
+}
 FDN_API int fdn_get_timers(fdn_handle h, double* ms_out, long long* count_out, int reset)
 {
     FDN_ENTER(h);

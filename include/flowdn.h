@@ -205,13 +205,17 @@ int fdn_permute_dev(fdn_handle h, const float* d_in, float* d_out, int A, int B,
 #define FDN_TIMER_TRANSFER 5         /* H2D / D2H                                               */
 #define FDN_TIMER_FUSED 6            /* fused Farneback chain-step kernel (fast path)           */
 #define FDN_TIMER_ITER 7             /* one-iteration Farneback kernel (wide windows)            */
-#define FDN_TIMER_COUNT 8
+#define FDN_TIMER_COLLECTIVE 8       /* multi-GPU exchanges; fed by the host layer (fdn_add_timer): the library is single-device */
+#define FDN_TIMER_COUNT 9
 /* HIP-event timing of the phases above on the handle's stream.  Event pairs are recorded
  * asynchronously (no host sync inside the timed work) and resolved by fdn_get_timers, which
  * returns accumulated milliseconds and the number of timed launches per category. */
 int fdn_enable_timers(fdn_handle h, int on);
 int fdn_get_timers(fdn_handle h, double* ms_out /* FDN_TIMER_COUNT */,
                    long long* count_out /* FDN_TIMER_COUNT */, int reset);
+/* Adds time measured outside the library to a category (the slab engine reports its RCCL exchanges as
+ * FDN_TIMER_COLLECTIVE, so that one table holds the whole taxonomy of gpu:47-53 plus the collectives). */
+int fdn_add_timer(fdn_handle h, int which, double ms, long long count);
 
 /* library/version string, e.g. "flowdn 0.1 gfx950" */
 const char* fdn_version(void);
