@@ -15,7 +15,8 @@
 //   wave 0 (producer)  row t         : M row from flow_in, R0 and the bilinear gather of R1 -> LDS ring slot t % RS
 //   wave 1 (consumer)  row t - MH - 1: OpenCV's vertical running sum vsum += f32(M[y+MH] - M[y-MH-1]) (carried in
 //                                      registers from row 0: the f32-fed recurrence is what makes results bit-faithful,
-//                                      DESIGN.md 3.2), horizontal window across lanes by doubling through LDS rows,
+//                                      DESIGN.md 3.2), horizontal window across lanes in two levels of blocks
+//                                      through LDS rows,
 //                                      2 x 2 solve, store
 //   wave 2 (warper)    row t - MH - 2: last iteration of level 0 only: the 1/32-px remap of the neighbour at p + flow
 //                                      and acc = f32(f64(acc) + f64(v) w) (seq:106-107); the flow comes from the
@@ -23,11 +24,20 @@
 //   one s_barrier per row step; the ring holds rows t - 2 MH - 1 .. t (RS = 2 MH + 2 rows x 1280 B): the slot the
 //   producer writes in step t held row t - 2 MH - 2, the consumer's trailing row of this step -- which it has read
 //   one step ahead, into registers.
-// LDS per workgroup at winsize 15: 20.0 KB ring + 5.3 KB doubling rows = 25.3 KB -> 6 workgroups = 12 waves per CU.
+// LDS per workgroup at winsize 15: 20.0 KB ring + 5.3 KB window rows = 25.3 KB -> 6 workgroups = 12 waves per CU.
 #include "fdn_internal.h"
 #include "fdn_device.h"
 
 namespace fdn {
+
+// Block length of the two-level window sum of n columns (see the consumer): floor(sqrt(n)), at least 2.
+// oracle/fdn_oracle.c box_mode 4 sums in the same order.
+static __host__ __device__ constexpr int window_block(int n)
+{
+    int p = 1;
+    while ((p + 1) * (p + 1) <= n) p++;
+    return p < 2 ? 2 : p;
+}
 
 static __device__ __forceinline__ void lds_barrier_iter()
 {
@@ -46,10 +56,11 @@ __global__ __launch_bounds__(ACC ? 192 : 128) void k_farneback_iter(const float*
     const int MH = MHT ? MHT : mh_rt;
     const int RS = 2 * MH + 2;
     const int BW = 64 - 2 * MH;
+    const int WP = window_block(2 * MH + 1), WQ = (2 * MH + 1) / WP, WREM = 2 * MH + 1 - WP * WQ, WE = MH % WP;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // ring row: [ (m0, m2) x 64 ][ (m3, m4) x 64 ][ m1 x 64 ] floats; then the consumer's window row: 5 x (64 + 2 MH) doubles
     float* ring = lds;
-    // the doubling rows (see the consumer): [2][XR] doubles, channel c's lane L at MH + 64 c + L.  Reads run up to MH
+    // the window rows (see the consumer): [2][XR] doubles, channel c's lane L at MH + 64 c + L.  Reads run up to MH
     // entries before and MH + 1 after a channel's 64: into the neighbouring channel or the padding at the row's ends --
     // values that only reach lanes whose results are never used (the band's halo lanes)
     double* xch = (double*)(lds + (size_t)RS * 320);
@@ -92,7 +103,9 @@ __global__ __launch_bounds__(ACC ? 192 : 128) void k_farneback_iter(const float*
         // the bilinear footprint of R1.  Three register sets rotate (the loop is unrolled by three) so that neither
         // hop is waited for in the step that issues it: step t loads flow/R0 of row t + 2, issues the gather of row
         // t + 1 (whose flow was loaded a step earlier) and turns row t into M.  (A register copy at the end of a step
-        // would make the wave wait for the loads right away.  Deeper pipelines measured: two steps for the flow / R0
+        // would make the wave wait for the loads right away.  Streaming (nt) loads of flow / R0 and nt stores of the new
+        // flow: 9 % slower -- the columns neighbouring bands share come out of L2.
+        // Deeper pipelines measured: two steps for the flow / R0
         // loads, four sets: the same time; two steps per hop, five sets: 164-196 VGPRs, two waves per SIMD, 10 % slower.)
         struct RowOps { float2 f; fdn_v2f r01, r23; float r4; int x1, y1; float fx, fy; GatherTapsP g; };
         auto load_ops = [&](int row, RowOps& o) __attribute__((always_inline)) {
@@ -187,40 +200,56 @@ __global__ __launch_bounds__(ACC ? 192 : 128) void k_farneback_iter(const float*
 #pragma unroll
             for (int c = 0; c < 5; c++) vs[c] += (double)(lead[c] - trail[c]);
             ring_row(y - MH > 0 ? y - MH : 0, trail);           // the next row's trailing row, while its slot still holds it
-            // Horizontal window of 2 MH + 1 columns by doubling: T1 = vsum, T2k[L] = Tk[L] + Tk[L + k] (the sum of 2k
-            // columns starting at L); the window is the sum of the Tk of its binary digits, lowest first:
-            // winsize 15: v[L+7] + T2[L+5] + T4[L+1] + T8[L-7].  6 additions and 11 LDS accesses per channel where the
-            // plain window takes 14 and 16 (and 150 registers when unrolled).  Two LDS rows per channel, recycled:
-            // a wave's LDS operations execute in order, so a row may be rewritten once the reads of its previous
+            // Horizontal window of n = 2 MH + 1 columns in two levels of blocks, through two LDS rows: with p =
+            // floor(sqrt(n)) (window_block), q = n / p, rem = n - p q,
+            //     B[L] = v[L-e] + ... + v[L-e+p-1]                (p consecutive columns, left to right; e = MH % p)
+            //     window[L] = B[L-MH+e] + B[L-MH+e+p] + ... (q blocks, left to right) + v[L+MH-rem+1] + ... + v[L+MH]
+            // e places one of the q blocks at offset 0 and the lane's own column inside B: both come from registers.
+            // winsize 15: p = 3, q = 5: 2 + 4 LDS reads, 2 writes and 6 additions per channel in TWO write -> read round
+            // trips.  (The consumer's row step is a chain of dependent LDS round trips, and that chain -- not the
+            // operation count -- is what the step waits for: summing the window by doubling, T2k[L] = Tk[L] + Tk[L+k],
+            // takes 7 reads, 4 writes, 6 additions but FOUR round trips: 16 % slower, 1.84 against 1.55 s per -l 3 -w 15
+            // volume; radix 4 then singles: 1.73 s; the plain 14-read window in one round trip: 2.2 s.)
+            // A wave's LDS operations execute in order, so a row may be rewritten once the reads of its previous
             // content have been issued; the fences only keep the compiler from reordering across them.
             // (Measured and rejected, all bit-identical: splitting the row into pipeline stages over consecutive steps
             // -- window sums / solve + tap issue / weighting -- 6 % slower; only deferring the remap taps' weighting to
             // the next step, the loop unrolled by two for the alternating tap registers: 6 % slower; two neighbouring
-            // bands per workgroup so that their shared columns come from HBM once: 5 % slower, four waves per barrier.)
-            double a[5], tk[5];
+            // bands per workgroup so that their shared columns come from HBM once: 5 % slower, four waves per barrier.
+            // With the two-level window: reading the leading row one step ahead as well (the consumer one more row
+            // behind): no change -- the step no longer waits for the consumer's chain.  Timing-only builds, same
+            // volume: producer alone 1.26 s, consumer alone 1.04 s, both 1.55 s.)
+            double a[5], blk[5];
+            {
+                double* row0 = xch;
+                double* row1 = xch + XR;
 #pragma unroll
-            for (int c = 0; c < 5; c++) tk[c] = vs[c];
-            int pos = MH;                       // column offset of the next term, counted down from the window's right end
-            bool first = true;
-            for (int k = 1, lvl = 0; k <= 2 * MH + 1; k <<= 1, lvl++) {
-                double* row = xch + (size_t)(lvl & 1) * XR;
-#pragma unroll
-                for (int c = 0; c < 5; c++) row[c * 64 + lane + MH] = tk[c];
+                for (int c = 0; c < 5; c++) row0[c * 64 + lane + MH] = vs[c];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const bool digit = ((2 * MH + 1) & k) != 0;
-                const bool more = 2 * k <= 2 * MH + 1;
-                if (digit) pos -= k;            // this digit's block starts at column offset pos + 1
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
-                    const double* r = row + c * 64 + lane + MH;
-                    if (digit) {
-                        const double term = r[pos + 1];
-                        a[c] = first ? term : a[c] + term;
-                    }
-                    if (more) tk[c] = tk[c] + r[k];
+                    const double* r = row0 + c * 64 + lane + MH;
+                    double s = WE == 0 ? vs[c] : r[-WE];
+                    for (int j = 1; j < WP; j++) s += j == WE ? vs[c] : r[j - WE];
+                    blk[c] = s;
+                    row1[c * 64 + lane + MH] = s;
                 }
-                if (digit) first = false;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    const double* r1 = row1 + c * 64 + lane + MH;
+                    const double* r0 = row0 + c * 64 + lane + MH;
+                    double s = 0.;
+                    for (int bk = 0; bk < WQ; bk++) {
+                        const int off = -MH + WE + WP * bk;
+                        const double term = off == 0 ? blk[c] : r1[off];
+                        s = bk == 0 ? term : s + term;
+                    }
+                    for (int j = 0; j < WREM; j++) s += r0[MH - WREM + 1 + j];
+                    a[c] = s;
+                }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }

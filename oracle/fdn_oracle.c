@@ -651,6 +651,47 @@ static void update_flow_blur(const float* R0, const float* R1, float* flow, floa
         if (update) update_matrices(R0, R1, flow, M, H, W, 0, H);
         return;
     }
+    if (box_mode == 4) {
+        /* OpenCV's vertical running sum, the horizontal window summed IN TWO LEVELS OF BLOCKS -- the order of the HIP
+         * path's one-iteration kernel (fdn_iter.hip, winsize >= 10): n = 2m + 1, p = max(2, floor(sqrt(n))), q = n / p,
+         * rem = n - p q; the window's first p q columns as q blocks of p consecutive columns (columns clamped to the
+         * image), each block summed left to right, the blocks added left to right, then the last rem columns one
+         * by one.  Exact -- hence equal to every other order -- whenever the f64 sums do not round. */
+        int wn = 2 * m + 1, p = 1;
+        while ((p + 1) * (p + 1) <= wn) p++;
+        if (p < 2) p = 2;
+        int q = wn / p, rem = wn - p * q;
+        double* vs = (double*)malloc((size_t)W * 5 * sizeof(double));
+        for (int x = 0; x < W * 5; x++) vs[x] = M[x] * (m + 2);
+        for (int y = 1; y < m; y++) {
+            const float* srow = M + (size_t)(y < H - 1 ? y : H - 1) * W * 5;
+            for (int x = 0; x < W * 5; x++) vs[x] += srow[x];
+        }
+        for (int y = 0; y < H; y++) {
+            float* fl = flow + (size_t)y * W * 2;
+            const float* s0 = M + (size_t)(y - m - 1 > 0 ? y - m - 1 : 0) * W * 5;
+            const float* s1 = M + (size_t)(y + m < H - 1 ? y + m : H - 1) * W * 5;
+            for (int x = 0; x < W * 5; x++) vs[x] += s1[x] - s0[x];
+            for (int x = 0; x < W; x++) {
+                double a[5];
+                for (int c = 0; c < 5; c++) {
+                    double s = 0;
+                    for (int b = 0; b < q; b++) {
+                        int c0 = x - m + b * p;
+                        double blk = vs[clampi(c0, 0, W - 1) * 5 + c];
+                        for (int j = 1; j < p; j++) blk += vs[clampi(c0 + j, 0, W - 1) * 5 + c];
+                        s = b == 0 ? blk : s + blk;
+                    }
+                    for (int j = 0; j < rem; j++) s += vs[clampi(x + m - rem + 1 + j, 0, W - 1) * 5 + c];
+                    a[c] = s;
+                }
+                solve_flow(a[0], a[1], a[2], a[3], a[4], scale, fl + x * 2);
+            }
+        }
+        free(vs);
+        if (update) update_matrices(R0, R1, flow, M, H, W, 0, H);
+        return;
+    }
     int y0 = 0, y1;
     int min_update_stripe = (1 << 10) / W > block_size ? (1 << 10) / W : block_size;
     double* _vsum = (double*)malloc((size_t)(W + m * 2 + 2) * 5 * sizeof(double));

@@ -22,7 +22,8 @@ INTER_AREA = 3
 BOX_RUNNING = 0   # OpenCV's running sums (faithful restatement)
 BOX_DIRECT = 1    # direct f64 window sums in both directions (for sensitivity studies)
 BOX_VRUN_HDIRECT = 2  # OpenCV's vertical running sum + direct f64 horizontal window: the kernels' order (winsize <= 9)
-BOX_VRUN_HDOUBLING = 3  # ... + the horizontal window summed by doubling: the one-iteration kernel's order (winsize >= 10)
+BOX_VRUN_HDOUBLING = 3  # ... + the horizontal window summed by doubling (an order the one-iteration kernel used before)
+BOX_VRUN_HBLOCKS = 4    # ... + the horizontal window as blocks of floor(sqrt(w)) columns: the one-iteration kernel's order (winsize >= 10)
 
 
 def build(force=False):

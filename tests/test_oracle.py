@@ -147,6 +147,27 @@ def test_running_vs_direct_box_sums(oracle):
     assert 0 < d < 1e-2
 
 
+@pytest.mark.parametrize("w", [3, 5, 7, 10, 11, 15, 21, 31, 49])
+def test_horizontal_summation_orders_agree(oracle, w):
+    """The oracle's horizontal-window orders -- OpenCV's running sum (0), left to right (2), by doubling (3), blocks of
+    floor(sqrt(w)) columns (4, the one-iteration HIP kernel's order) -- are the same sum: bit-identical flows when the
+    f64 sums cannot round (small-integer matrices), and equal to f64 rounding on ordinary data."""
+    rng = np.random.default_rng(100 + w)
+    H, W = 40, 150
+    R = rng.standard_normal((H, W, 5)).astype(np.float32)
+    z = np.zeros((H, W, 2), np.float32)
+    Mi = rng.integers(-50, 50, (H, W, 5)).astype(np.float32)
+    Mi[..., 0] += 200; Mi[..., 2] += 200           # keep the 2 x 2 systems well conditioned
+    Mr = Mi + rng.standard_normal((H, W, 5)).astype(np.float32)
+    modes = (oracle.BOX_RUNNING, oracle.BOX_VRUN_HDIRECT, oracle.BOX_VRUN_HDOUBLING, oracle.BOX_VRUN_HBLOCKS)
+    exact = [oracle.update_flow_blur(R, R, z, Mi, w, False, box_mode=m)[0] for m in modes]
+    for f in exact[1:]:
+        assert np.array_equal(f, exact[0])
+    close = [oracle.update_flow_blur(R, R, z, Mr, w, False, box_mode=m)[0] for m in modes]
+    for f in close[1:]:
+        np.testing.assert_allclose(f, close[0], rtol=0, atol=1e-6 * np.abs(close[0]).max())
+
+
 def test_constant_volume(oracle):
     """KAT 5: constant volume v (pad = v) -> v * sum(w) per pass."""
     vol = np.full((5, 34, 36), 12.5, np.float32)

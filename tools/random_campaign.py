@@ -23,7 +23,7 @@ for i, (shape, axis, l, w, sigma, border, chained, seed) in enumerate(cases):
     if np.array_equal(got, want):
         exact += 1
     else:
-        want2 = oracle.filter_along_axis(vol, axis, k, l, w, mean, border_mode=border, chained=chained, box_mode=3 if w >= 10 else 2, nthreads=8)
+        want2 = oracle.filter_along_axis(vol, axis, k, l, w, mean, border_mode=border, chained=chained, box_mode=4 if w >= 10 else 2, nthreads=8)
         err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
         kind = "f64 summation order only" if np.array_equal(got, want2) else "REAL MISMATCH"
         print(kind, (shape, axis, l, w, sigma, border, chained, seed), err, flush=True)

@@ -23,7 +23,7 @@ for i in range(n):
     want = oracle.filter_along_axis(vol, axis, k, l, w, mean, border_mode=border, chained=chained, nthreads=16)
     if not np.array_equal(got, want):
         # the only designed difference: OpenCV's serial f64 running sum along x against the kernels' direct window sum
-        want2 = oracle.filter_along_axis(vol, axis, k, l, w, mean, border_mode=border, chained=chained, box_mode=3 if w >= 10 else 2, nthreads=16)
+        want2 = oracle.filter_along_axis(vol, axis, k, l, w, mean, border_mode=border, chained=chained, box_mode=4 if w >= 10 else 2, nthreads=16)
         err = np.abs(got - want).max() / np.abs(want).max()
         kind = "f64 summation order only" if np.array_equal(got, want2) else "REAL MISMATCH"
         bad += kind == "REAL MISMATCH"
