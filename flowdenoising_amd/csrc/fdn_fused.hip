@@ -46,7 +46,9 @@ namespace fdn {
 // Whole-wave lane shifts of an f64 on the VALU (DPP wave_shr:1 / wave_shl:1): lane i receives the
 // value of lane i-1 (i+1); the lane shifted in from outside the wave reads 0 (bound_ctrl), which only
 // reaches halo lanes whose results are never used.  Measured on MI355X (tools/ubench/rates.hip): ~5 cycles per v_mov_dpp per
-// SIMD against 24 cycles per ds_bpermute_b32 on the one LDS pipe the four SIMDs share.
+// SIMD against 24 cycles per ds_bpermute_b32 on the one LDS pipe the four SIMDs share.  (Also measured: the window
+// through an LDS row per stage -- 5 ds_write_b64 + 10 ds_read2_b64 in place of 40 v_mov_dpp per row step, the R1
+// window cut to D = 4 to make room: 18.9 ms per launch against 17.8 with D = 4 alone and 16.9 as built.)
 static __device__ __forceinline__ double wave_shr1(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);

@@ -137,3 +137,35 @@ def test_config4_uint16_tiff_cli_end_to_end(fdn, oracle, tmp_path):
     # a float32 difference below TIGHT_TOL may still cross an integer boundary under truncation
     diff = np.abs(got.astype(np.int32) - want16.astype(np.int32))
     assert diff.max() <= 1 and np.count_nonzero(diff) <= 1e-6 * diff.size, (int(diff.max()), int(np.count_nonzero(diff)))
+
+
+def test_config4_full_volume(fdn, oracle):
+    """configs[4] whole: 2048 x 2048 x 512 voxels (8 GiB as float32) of uint16-range data, sigma = (2, 2, 4), -l 3 -w 15,
+    Z, Y and X passes on one GPU in one call.  The volume is generated on the device (the host never holds it); the
+    result must equal a pass-by-pass rerun bit for bit, and one target slice of every pass -- recomputed by the oracle
+    from the GPU's own input of that pass -- must match (bench.py's check, here at configs[4]'s size)."""
+    import torch
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    from flowdenoising_amd import _lib
+    from flowdenoising_amd.synth import make_volume
+    free, _total = torch.cuda.mem_get_info()
+    if free < 120 * 2**30:
+        pytest.skip("needs 120 GiB of free device memory")
+    shape = (512, 2048, 2048)
+    dev = torch.device("cuda", 0)
+    vol = make_volume(shape, seed=1234 + 5, amplitude=100.0, xp=torch, device=dev)
+    lo, hi = float(vol.min()), float(vol.max())
+    vol = torch.round((vol - lo) / (hi - lo) * 4095)            # what a 12-bit detector stack holds, as float32 (seq:517)
+    kernels = [fdn.get_gaussian_kernel(s) for s in (2.0, 2.0, 4.0)]
+    params = _lib.SweepParams(3, 15, 3, 5, 1.2, _lib.BORDER_MEAN_PAD, 1, 1)
+    h = _lib.Handle(0)
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    out = torch.empty_like(vol)
+    mean = h.mean_dev(vol.data_ptr(), vol.numel())
+    h.filter_3d_dev(vol.data_ptr(), out.data_ptr(), shape, kernels, mean, params)
+    torch.cuda.synchronize()
+    res = bench.check_output(h, vol, out, shape, kernels, params, mean)
+    assert res["timed_output_equals_pass_by_pass_rerun"], res
+    assert res["max_rel_err"] < TIGHT_TOL, res
