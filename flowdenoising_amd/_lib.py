@@ -24,7 +24,18 @@ class SweepParams(ctypes.Structure):
     """struct fdn_sweep_params"""
     _fields_ = [("levels", ctypes.c_int), ("winsize", ctypes.c_int), ("iters", ctypes.c_int),
                 ("poly_n", ctypes.c_int), ("poly_sigma", ctypes.c_double),
-                ("border_mode", ctypes.c_int), ("chained", ctypes.c_int), ("use_of", ctypes.c_int)]
+                ("border_mode", ctypes.c_int), ("chained", ctypes.c_int), ("use_of", ctypes.c_int),
+                # integer-volume semantics (include/flowdn.h); all zero = float32
+                ("warp_mode", ctypes.c_int), ("pad_lo", ctypes.c_int), ("pad_hi", ctypes.c_int),
+                ("pad64", ctypes.c_double), ("round_lo", ctypes.c_double), ("round_hi", ctypes.c_double)]
+
+    def copy(self):
+        c = SweepParams()
+        ctypes.memmove(ctypes.byref(c), ctypes.byref(self), ctypes.sizeof(SweepParams))
+        return c
+
+
+WARP_F32, WARP_F64_PADDED, WARP_ROUND_INT = 0, 1, 2
 
 
 # every symbol include/flowdn.h declares (tests check the .so exports all of them)

@@ -101,7 +101,7 @@ def _run_sharded(args, shape, kernels, l, w):
     from . import _lib
     from . import io as fio
     from .distributed import SlabEngine, SlabPlan
-    from .operators import _params
+    from .operators import _params, integer_semantics
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", rank))
     if torch.cuda.device_count() >= world:          # one GPU per rank, exchanges over RCCL / xGMI
@@ -115,14 +115,21 @@ def _run_sharded(args, shape, kernels, l, w):
         dist.init_process_group("gloo")
         logging.warning(f"--gpus {world} on a node with {torch.cuda.device_count()} GPU(s): the ranks share GPU 0")
     plan = SlabPlan(shape, world, rank)
-    mine = np.ascontiguousarray(fio.read_slab(args.input, plan.z0, plan.z0 + plan.zlen), dtype=np.float32)   # seq:517
+    raw = fio.read_slab(args.input, plan.z0, plan.z0 + plan.zlen)
+    border = _lib.BORDER_WRAP if args.compat == "par" else _lib.BORDER_MEAN_PAD
+    params = integer_semantics(raw, _params(l, w, use_of=not args.no_OF, border_mode=border, chained=not args.recompute_flow))
+    mean = None
+    if params.warp_mode == _lib.WARP_F64_PADDED:    # an integer MRC (seq:513): numpy's float64 mean of the WHOLE volume = exact integer sum / count
+        tot = torch.tensor([int(raw.sum(dtype=np.int64))], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tot)
+        params.pad64 = float(int(tot.item())) / float(shape[0] * shape[1] * shape[2])
+        mean = np.float32(params.pad64)
+    mine = np.ascontiguousarray(raw, dtype=np.float32)   # seq:517
     slab = torch.from_numpy(mine).to(dev)
     h = _lib.Handle(local)
     h.set_stream(torch.cuda.current_stream().cuda_stream)
-    border = _lib.BORDER_WRAP if args.compat == "par" else _lib.BORDER_MEAN_PAD
-    params = _params(l, w, use_of=not args.no_OF, border_mode=border, chained=not args.recompute_flow)
     eng = SlabEngine(plan, h, dist)
-    out = eng.filter_3d(slab, kernels, params)
+    out = eng.filter_3d(slab, kernels, params, mean=mean)
     full = eng.gather_z_slabs(out, 0)               # slabs may differ in length: point-to-point into their place, rank 0 only
     res = full.cpu().numpy() if rank == 0 else None
     logging.info(f"rank {rank} phases (ms): " + ", ".join(f"{k} {v:.1f}" for k, v in eng.phase_times().items()))

@@ -271,7 +271,22 @@ static int check_params(const fdn_sweep_params* p, int K)
         if (p->iters < 0) return fail("iters must be >= 0");
         if (p->levels < 0) return fail("levels must be >= 0");
     }
+    if (p->warp_mode < 0 || p->warp_mode > 2) return fail("warp_mode must be FDN_WARP_F32, _F64_PADDED or _ROUND_INT, got %d", p->warp_mode);
+    if (p->warp_mode == FDN_WARP_F64_PADDED && p->border_mode != FDN_BORDER_MEAN_PAD)
+        return fail("FDN_WARP_F64_PADDED belongs to the mean-padded volume of seq:88-89 (border_mode FDN_BORDER_MEAN_PAD)");
+    if (p->warp_mode == FDN_WARP_F64_PADDED && (p->pad_lo < 0 || p->pad_hi < 0)) return fail("pad_lo / pad_hi must be >= 0");
+    if (p->warp_mode == FDN_WARP_ROUND_INT && !(p->round_lo < p->round_hi)) return fail("FDN_WARP_ROUND_INT needs round_lo < round_hi");
     return 0;
+}
+
+// fdn_sweep_params -> what the folding kernels need; pad slices in the coordinates of a stack of S + 2r slices
+static WarpMode warp_mode_of(const fdn_sweep_params* p, int S, int r)
+{
+    WarpMode wm;
+    wm.kind = p->warp_mode;
+    if (wm.kind == FDN_WARP_F64_PADDED) { wm.pad_lo = p->pad_lo; wm.pad_hi = S + 2 * r - p->pad_hi; wm.pad64 = p->pad64; }
+    if (wm.kind == FDN_WARP_ROUND_INT) { wm.lo = (float)p->round_lo; wm.hi = (float)p->round_hi; }
+    return wm;
 }
 
 // number of pyramid levels OpenCV actually uses (calc(): min_size = 32)
@@ -556,11 +571,14 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
     const int r = K / 2;
     const size_t HW = (size_t)H * W;
     hipStream_t st = h->stream;
+    const WarpMode wm_all = warp_mode_of(p, S, r);   // pad slices in the coordinates of the whole stack
+    const bool plain = wm_all.kind == FDN_WARP_F32;  // otherwise: flows from the Farneback kernels, folding by k_sweep_side
 
     if (!p->use_of) { // seq:184-185: taps in index order
         ScopedTimer t(h, FDN_TIMER_WARP);
         launch_fill(out, 0.f, (size_t)S * HW, st);
-        for (int i = 0; i < K; i++) launch_axpy_slices(stack, out, PairBatch{S, r, i - r}, H, W, kernel[i], st);
+        for (int i = 0; i < K; i++) launch_axpy_slices(stack, out, PairBatch{S, r, i - r}, H, W, kernel[i], st, wm_all);
+        if (wm_all.kind == FDN_WARP_ROUND_INT) launch_trunc_clamp(out, (size_t)S * HW, wm_all.lo, wm_all.hi, st);
         FDN_HIP(hipGetLastError());
         return 0;
     }
@@ -618,6 +636,8 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
     const int nr = std::min(CR, S - cr0);
     stack = stack_all + (size_t)cr0 * HW;        // the batch's own stack: target q is its slice q + r
     out = out_all + (size_t)cr0 * HW;
+    WarpMode wm = wm_all;
+    wm.pad_lo = std::max(0, wm_all.pad_lo - cr0); wm.pad_hi = wm_all.pad_hi - cr0;
     {
         ScopedTimer t(h, FDN_TIMER_POLYEXP);
         launch_blur3_polyexp(stack, R, nr + 2 * r, H, W, pc, st);
@@ -635,6 +655,20 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
                 for (int step = 0; step < r; step++) {
                     int d = side == 0 ? -(step + 1) : (step + 1); // nearest neighbour first (seq:95,110)
                     bool keep = p->chained && step + 1 < r;       // the next step is seeded with this flow (seq:98)
+                    if (!plain) {   // the flow only; the neighbour is sampled and folded in by k_sweep_side in the volume's mode
+                        if (pyramid) {
+                            if (pyramid_step_fused(h, lv, R, stack, fin, fout, nullptr, PairBatch{n, r + c0, d}, H, W, p->winsize, p->iters, 0.0)) return -1;
+                        } else {
+                            ScopedTimer t(h, FDN_TIMER_FUSED);
+                            launch_farneback_fused(R, stack, fin, fout, nullptr, PairBatch{n, r + c0, d}, H, W, p->winsize, p->iters, 0.0, st, h->tn);
+                        }
+                        {
+                            ScopedTimer t(h, FDN_TIMER_WARP);
+                            launch_sweep_side(stack, fout, acc, PairBatch{n, r + c0, side == 0 ? -1 : 1}, 1, step, H, W, &kernel[r + d], st, wm);
+                        }
+                        if (keep) { fin = fout; fout = fout == flow ? flowB : flow; }
+                        continue;
+                    }
                     if (pyramid) {
                         if (pyramid_step_fused(h, lv, R, stack, fin, keep ? fout : nullptr, acc, PairBatch{n, r + c0, d}, H, W,
                                                p->winsize, p->iters, kernel[r + d])) return -1;
@@ -655,6 +689,13 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
                     int d = side == 0 ? -(step + 1) : (step + 1);
                     bool keep = p->chained && step + 1 < r;
                     float* res = nullptr;
+                    if (!plain) {
+                        if (chain_step_iter(h, lv, R, stack, prev, bufs, nullptr, PairBatch{n, r + c0, d}, H, W, p->winsize, p->iters, 0.0, true, &res)) return -1;
+                        ScopedTimer t(h, FDN_TIMER_WARP);
+                        launch_sweep_side(stack, res, acc, PairBatch{n, r + c0, side == 0 ? -1 : 1}, 1, step, H, W, &kernel[r + d], st, wm);
+                        prev = keep ? res : nullptr;
+                        continue;
+                    }
                     if (chain_step_iter(h, lv, R, stack, prev, bufs, acc, PairBatch{n, r + c0, d}, H, W, p->winsize, p->iters,
                                         kernel[r + d], keep, &res)) return -1;
                     prev = keep ? res : nullptr;
@@ -678,14 +719,15 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
                 for (int step = 0; step < r; step++) wts[step] = kernel[side == 0 ? r - 1 - step : r + 1 + step];
                 // steps of a batch smaller than C are still C * HW * 2 floats apart: one launch per step stride needs
                 // npairs == C, so a short last batch folds step by step
-                if (n == C) launch_sweep_side(stack, flow, acc, PairBatch{n, r + c0, side == 0 ? -1 : 1}, r, 0, H, W, wts.data(), st);
+                if (n == C) launch_sweep_side(stack, flow, acc, PairBatch{n, r + c0, side == 0 ? -1 : 1}, r, 0, H, W, wts.data(), st, wm);
                 else
                     for (int step = 0; step < r; step++)
-                        launch_sweep_side(stack, flow + (size_t)step * C * HW * 2, acc, PairBatch{n, r + c0, side == 0 ? -1 : 1}, 1, step, H, W, &wts[step], st);
+                        launch_sweep_side(stack, flow + (size_t)step * C * HW * 2, acc, PairBatch{n, r + c0, side == 0 ? -1 : 1}, 1, step, H, W, &wts[step], st, wm);
             }
         }
     }
     }   // batches of R
+    if (wm_all.kind == FDN_WARP_ROUND_INT) launch_trunc_clamp(out_all, (size_t)S * HW, wm_all.lo, wm_all.hi, st);   // par:131, 287: the integer volume takes the pass
     FDN_HIP(hipGetLastError());
     return 0;
 }
@@ -717,6 +759,7 @@ static int filter_axis_dev(fdn_ctx* h, const float* d_in, float* d_out, int Z, i
     if (axis < 0 || axis > 2) return fail("axis must be 0, 1 or 2");
     if (Z <= 0 || Y <= 0 || X <= 0) return fail("bad volume dims");
     if (d_in == d_out) return fail("in and out must not alias");
+    if (p->warp_mode == FDN_WARP_F64_PADDED) pad_value = (float)p->pad64;     // what Farneback's convertTo(CV_32F) makes of the float64 pad slices
     int S, H, W;
     axis_dims(Z, Y, X, axis, &S, &H, &W);
     const int r = K / 2;
@@ -762,7 +805,10 @@ static int filter_axis_dev(fdn_ctx* h, const float* d_in, float* d_out, int Z, i
             }
         }
         float* sw_out = axis == 0 ? d_out + (size_t)s0 * HW : (float*)h->sweep_out.p;
-        if (sweep_stack(h, stack, sw_out, np, H, W, kernel, K, p)) return -1;
+        fdn_sweep_params pc = *p;         // this chunk's pad slices (seq:88-89): before slice 0, after slice S - 1
+        pc.pad_lo = p->border_mode == FDN_BORDER_MEAN_PAD ? std::min(std::max(0, r - s0), np + 2 * r) : 0;
+        pc.pad_hi = p->border_mode == FDN_BORDER_MEAN_PAD ? std::min(std::max(0, s0 + np + r - S), np + 2 * r) : 0;
+        if (sweep_stack(h, stack, sw_out, np, H, W, kernel, K, &pc)) return -1;
         if (axis != 0) {
             ScopedTimer t(h, FDN_TIMER_PERMUTE);
             if (axis == 1)      // out[z][s0 + yy][x] = t[yy][z][x]

@@ -269,6 +269,17 @@ static __device__ __forceinline__ float remap_finish(const RemapTaps& r)
     return r.v0 * w0 + r.v1 * w1 + r.v2 * w2 + r.v3 * w3;
 }
 
+// cv2.remap of a CV_64F image (remapBilinear<Cast<double, double>, ., float>): the float table weights widened, the four
+// products and three sums in double, no rounding to float.  pad: the image is the constant `padv` (a mean-pad slice).
+static __device__ __forceinline__ double remap_finish_f64(const RemapTaps& r, bool pad, double padv)
+{
+    float tx1 = (float)r.ax * (1.f / 32), tx0 = 1.f - tx1;
+    float ty1 = (float)r.ay * (1.f / 32), ty0 = 1.f - ty1;
+    float w0 = ty0 * tx0, w1 = ty0 * tx1, w2 = ty1 * tx0, w3 = ty1 * tx1;
+    const double v0 = pad ? padv : (double)r.v0, v1 = pad ? padv : (double)r.v1, v2 = pad ? padv : (double)r.v2, v3 = pad ? padv : (double)r.v3;
+    return v0 * (double)w0 + v1 * (double)w1 + v2 * (double)w2 + v3 * (double)w3;
+}
+
 static __device__ __forceinline__ float remap_sample(const float* __restrict__ src, int H, int W, int x, int y, float2 f)
 {
     RemapTaps r;

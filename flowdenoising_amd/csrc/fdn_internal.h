@@ -57,11 +57,18 @@ void launch_update_flow(const float* Rstack, const float* Min, float* Mout, floa
                         PairBatch pb, int H, int W, int winsize, hipStream_t st);
 // The whole side of a pass in one launch: for step s = 0 .. nsteps-1 (nearest neighbour first), neighbour
 // stack[t0 + b + pb.d * (first_step + s + 1)] warped by flows[s][b] and folded into acc[b] with weights[s]; pb.d = -1 / +1.
+// How a neighbour is sampled and folded in (fdn_sweep_params.warp_mode): kind 0 = float32 (seq / par on float data);
+// 1 = the padded volume is float64 (seq on an integer MRC): remap weights in double, stack slices [0, pad_lo) and
+// [pad_hi, ...) hold the float64 value pad64; 2 = the neighbour is an integer image (par on an integer MRC): remap's
+// result is rounded half-to-even and saturated to [lo, hi].
+struct WarpMode { int kind = 0; int pad_lo = 0, pad_hi = 1 << 30; double pad64 = 0.; float lo = 0.f, hi = 0.f; };
 void launch_sweep_side(const float* stack, const float* flows, float* acc, PairBatch pb, int nsteps, int first_step,
-                       int H, int W, const double* weights, hipStream_t st);
+                       int H, int W, const double* weights, hipStream_t st, const WarpMode& wm = WarpMode());
 // acc[b] = f32( f64(acc[b]) + f64(stack[t0 + b + d]) * weight )   (centre tap, no-OF taps)
 void launch_axpy_slices(const float* stack, float* acc, PairBatch pb, int H, int W,
-                        double weight, hipStream_t st);
+                        double weight, hipStream_t st, const WarpMode& wm = WarpMode());
+// v = trunc(v) clamped to [lo, hi]: a float32 result stored into an integer volume (par:131, par:287)
+void launch_trunc_clamp(float* v, size_t count, float lo, float hi, hipStream_t st);
 // dst(y,x) = remap(src, flow)  single image (fdn_warp)
 void launch_warp(const float* src, const float* flow, float* dst, int H, int W, hipStream_t st);
 

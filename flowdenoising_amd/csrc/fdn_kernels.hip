@@ -463,10 +463,10 @@ void launch_update_flow(const float* Rstack, const float* Min, float* Mout, floa
 constexpr int SWEEP_MAX_STEPS = 48;
 struct SweepWeights { double w[SWEEP_MAX_STEPS]; };
 
-template <int U>
+template <int U, int MODE>
 __global__ __launch_bounds__(256) void k_sweep_side(const float* __restrict__ stack, const float* __restrict__ flows,
                                                     float* __restrict__ acc_base, PairBatch pb, int nsteps, int first_step,
-                                                    int H, int W, SweepWeights sw)
+                                                    int H, int W, SweepWeights sw, WarpMode wm)
 {
     const size_t HW = (size_t)H * W;
     const int b = blockIdx.z;
@@ -495,7 +495,16 @@ __global__ __launch_bounds__(256) void k_sweep_side(const float* __restrict__ st
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
-            if (s0 + u < nsteps) a = (float)((double)a + (double)remap_finish(t[u]) * sw.w[s0 + u]);
+            if (s0 + u < nsteps) {
+                if (MODE == 1) {          // float64 padded volume (seq on integer input)
+                    const int q = pb.t0 + b + dir * (first_step + s0 + u + 1);
+                    a = (float)((double)a + remap_finish_f64(t[u], q < wm.pad_lo || q >= wm.pad_hi, wm.pad64) * sw.w[s0 + u]);
+                } else if (MODE == 2) {   // integer neighbour image (par on integer input): saturate_cast<T>(float) = cvRound, clamped
+                    const float v = fminf(fmaxf(rintf(remap_finish(t[u])), wm.lo), wm.hi);
+                    a = (float)((double)a + (double)v * sw.w[s0 + u]);
+                } else
+                    a = (float)((double)a + (double)remap_finish(t[u]) * sw.w[s0 + u]);
+            }
     }
     acc[o] = a;
 }
@@ -503,7 +512,7 @@ __global__ __launch_bounds__(256) void k_sweep_side(const float* __restrict__ st
 // acc[b] <- fold of steps first_step .. first_step + nsteps - 1 of side pb.d (= -1 or +1); weights[s] belongs to step
 // first_step + s; flows points at step first_step's flows.
 void launch_sweep_side(const float* stack, const float* flows, float* acc, PairBatch pb, int nsteps, int first_step,
-                       int H, int W, const double* weights, hipStream_t st)
+                       int H, int W, const double* weights, hipStream_t st, const WarpMode& wm)
 {
     if (pb.npairs <= 0) return;
     dim3 grid((W + 63) / 64, (H + 3) / 4, pb.npairs);
@@ -512,7 +521,10 @@ void launch_sweep_side(const float* stack, const float* flows, float* acc, PairB
         const int n = nsteps - s0 < SWEEP_MAX_STEPS ? nsteps - s0 : SWEEP_MAX_STEPS;
         SweepWeights sw;
         for (int i = 0; i < n; i++) sw.w[i] = weights[s0 + i];
-        hipLaunchKernelGGL(k_sweep_side<8>, grid, dim3(256), 0, st, stack, flows + (size_t)s0 * step_stride, acc, pb, n, first_step + s0, H, W, sw);
+        const float* fl = flows + (size_t)s0 * step_stride;
+        if (wm.kind == 1) hipLaunchKernelGGL((k_sweep_side<8, 1>), grid, dim3(256), 0, st, stack, fl, acc, pb, n, first_step + s0, H, W, sw, wm);
+        else if (wm.kind == 2) hipLaunchKernelGGL((k_sweep_side<8, 2>), grid, dim3(256), 0, st, stack, fl, acc, pb, n, first_step + s0, H, W, sw, wm);
+        else hipLaunchKernelGGL((k_sweep_side<8, 0>), grid, dim3(256), 0, st, stack, fl, acc, pb, n, first_step + s0, H, W, sw, wm);
     }
 }
 
@@ -532,20 +544,39 @@ void launch_warp(const float* src, const float* flow, float* dst, int H, int W, 
 }
 
 __global__ __launch_bounds__(256) void k_axpy_slices(const float* __restrict__ stack, float* __restrict__ acc_base,
-                                                     PairBatch pb, size_t HW, double weight)
+                                                     PairBatch pb, size_t HW, double weight, WarpMode wm)
 {
     const int b = blockIdx.y;
-    const float* src = stack + (size_t)(pb.t0 + b + pb.d) * HW;
+    const int q = pb.t0 + b + pb.d;
+    const float* src = stack + (size_t)q * HW;
     float* acc = acc_base + (size_t)b * HW;
+    if (wm.kind == 1 && (q < wm.pad_lo || q >= wm.pad_hi)) {     // a pad slice of a float64 padded volume
+        const double term = wm.pad64 * weight;
+        for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < HW; o += (size_t)gridDim.x * 256)
+            acc[o] = (float)((double)acc[o] + term);
+        return;
+    }
     for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < HW; o += (size_t)gridDim.x * 256)
         acc[o] = (float)((double)acc[o] + (double)src[o] * weight);
 }
-void launch_axpy_slices(const float* stack, float* acc, PairBatch pb, int H, int W, double weight, hipStream_t st)
+void launch_axpy_slices(const float* stack, float* acc, PairBatch pb, int H, int W, double weight, hipStream_t st, const WarpMode& wm)
 {
     if (pb.npairs <= 0) return;
     size_t HW = (size_t)H * W;
     int gx = (int)((HW + 255) / 256); if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(k_axpy_slices, dim3(gx, pb.npairs), dim3(256), 0, st, stack, acc, pb, HW, weight);
+    hipLaunchKernelGGL(k_axpy_slices, dim3(gx, pb.npairs), dim3(256), 0, st, stack, acc, pb, HW, weight, wm);
+}
+
+__global__ __launch_bounds__(256) void k_trunc_clamp(float* __restrict__ v, size_t count, float lo, float hi)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
+        v[i] = fminf(fmaxf(truncf(v[i]), lo), hi);
+}
+void launch_trunc_clamp(float* v, size_t count, float lo, float hi, hipStream_t st)
+{
+    if (!count) return;
+    size_t g = (count + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_trunc_clamp, dim3((unsigned)g), dim3(256), 0, st, v, count, lo, hi);
 }
 
 __global__ __launch_bounds__(256) void k_fill(float* __restrict__ dst, float value, size_t count)

@@ -330,6 +330,7 @@ class SlabEngine:
             stack[:lo].fill_(float(mean))
         if hi < e - s + 2 * r:
             stack[hi:].fill_(float(mean))
+        return lo, e - s + 2 * r - hi       # leading / trailing pad slices
 
     # -- seq:420 for a sharded volume ----------------------------------------------------------------
     def global_mean(self, vol):
@@ -418,11 +419,15 @@ class SlabEngine:
             n_loc, H, W = e - s, dims[1], dims[2]
             stack = self._buf(f"stack{axis}", (n_loc + 2 * r) * H * W, vol)[:(n_loc + 2 * r) * H * W].view(n_loc + 2 * r, H, W)
             self._exchange(cur, cur_axis, axis, r, wrap, stack)
+            pp = params
             if not wrap:
-                self._fill_pad(stack, axis, r, mean)
+                npl, nph = self._fill_pad(stack, axis, r, mean)
+                if getattr(params, "warp_mode", 0) == 1:      # FDN_WARP_F64_PADDED: the library needs to know the pad slices
+                    pp = params.copy()
+                    pp.pad_lo, pp.pad_hi = npl, nph
             out = self._buf(f"out{axis}", n_loc * H * W, vol)[:n_loc * H * W].view(n_loc, H, W)
             with self._phase("compute", vol):
-                self.backend.sweep_stack(stack, out, n_loc, H, W, k, params)
+                self.backend.sweep_stack(stack, out, n_loc, H, W, k, pp)
             cur, cur_axis = out, axis
         if cur_axis != 0:
             res = self._buf("result", vol.numel(), vol)[:vol.numel()].view(vol.shape)

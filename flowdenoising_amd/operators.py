@@ -68,7 +68,15 @@ def warp_slice(reference, flow, device=0):
 
 
 def _filter_axis(vol, axis, kernel, l, w, mean, use_of, border_mode, chained, device):
-    return handle(device).filter_axis(vol, axis, kernel, mean, _params(l, w, use_of, border_mode, chained))
+    p = _params(l, w, use_of, border_mode, chained)
+    if border_mode == _lib.BORDER_MEAN_PAD and not isinstance(mean, np.float32):
+        # seq:88: np.full(..., fill_value=mean) takes the DTYPE OF `mean`: anything but a numpy float32 (vol.mean() of an
+        # integer volume, a Python float) makes the padded volume float64 -- for a float32 `vol` too
+        p.warp_mode = _lib.WARP_F64_PADDED
+        p.pad64 = float(mean)
+    elif border_mode != _lib.BORDER_MEAN_PAD:
+        p = integer_semantics(vol, p)
+    return handle(device).filter_axis(vol, axis, kernel, mean, p)
 
 
 def OF_filter_along_Z(vol, kernel, l, w, mean, border_mode=_lib.BORDER_MEAN_PAD, chained=True, device=0):
@@ -95,6 +103,34 @@ def no_OF_filter_along_X(vol, kernel, mean, device=0):
     return _filter_axis(vol, 2, kernel, 0, OF_WINDOW_SIZE, mean, False, _lib.BORDER_MEAN_PAD, True, device)
 
 
+def integer_semantics(vol, params):
+    """What the reference does with a volume that is not float32 (an int8/int16/uint16 MRC keeps its dtype, seq:513,
+    par:472), as fdn_sweep_params fields (include/flowdn.h, FDN_WARP_*).  Returns params (a copy when changed).
+      mean-padded (seq): vol.mean() is a float64, hence a float64 padded volume (seq:88-89): cv2.remap weights in
+        double, the pad slices hold the float64 mean;
+      wrap-around (par): neighbour slices are integer images: cv2.remap rounds and saturates, each pass is truncated
+        into the integer volume (par:131, 287-289).  cv2.remap has no CV_8S path (the reference raises there) and its
+        CV_8U path interpolates in fixed point, which is not restated here."""
+    vol = np.asarray(vol)
+    if not np.issubdtype(vol.dtype, np.integer):
+        return params
+    if vol.dtype.itemsize > 2:
+        raise ValueError(f"{vol.dtype} volumes are not supported: float32 holds 8- and 16-bit integers exactly, not wider ones")
+    p = params.copy()
+    if params.border_mode == _lib.BORDER_MEAN_PAD:
+        p.warp_mode = _lib.WARP_F64_PADDED
+        p.pad64 = float(vol.mean())              # seq:420 on an integer array: numpy's float64 mean
+    else:
+        if params.use_of and vol.dtype == np.int8:
+            raise ValueError("cv2.remap does not accept 8-bit signed images (the reference fails on a mode-0 MRC here)")
+        if params.use_of and vol.dtype == np.uint8:
+            raise NotImplementedError("cv2.remap interpolates 8-bit unsigned images in fixed point; that path is not restated")
+        info = np.iinfo(vol.dtype)
+        p.warp_mode = _lib.WARP_ROUND_INT
+        p.round_lo, p.round_hi = float(info.min), float(info.max)
+    return p
+
+
 def _as_f32(vol):
     vol = np.asarray(vol)
     if vol.ndim != 3:
@@ -105,6 +141,7 @@ def _as_f32(vol):
 def filter_3d_own_mean(vol, kernel, params, device=0):
     """Upload, take vol.mean() (seq:420) on the GPU -- fdn_mean_dev reproduces numpy's float32 reduction bit
     for bit, and a 2 GiB volume costs numpy 0.3 s on the host -- run the passes, download."""
+    params = integer_semantics(vol, params)
     vol = _as_f32(vol)
     h = handle(device)
     d_in = h.malloc(vol.nbytes)
@@ -119,7 +156,8 @@ def filter_3d_own_mean(vol, kernel, params, device=0):
             finally:
                 if pin_in:
                     h.host_unregister(vol)
-            mean = h.mean_dev(d_in, vol.size)
+            # an integer volume's mean is numpy's float64 one (params.pad64); Farneback sees it as float32
+            mean = np.float32(params.pad64) if params.warp_mode == _lib.WARP_F64_PADDED else h.mean_dev(d_in, vol.size)
             h.filter_3d_dev(d_in, d_out, vol.shape, kernel, mean, params)
             pin_out = big and h.host_register(out)
             try:
@@ -160,7 +198,7 @@ class GaussianDenoising:
         self.device = 0
 
     def filter(self, kernels):
-        p = _params(self.l, self.w, self.use_of, _lib.BORDER_WRAP, self.chained)
+        p = integer_semantics(self.vol, _params(self.l, self.w, self.use_of, _lib.BORDER_WRAP, self.chained))
         out = handle(self.device).filter_3d(_as_f32(self.vol), kernels, 0.0, p)
         # par:131,287: results are stored in arrays of the INPUT dtype
         self.filtered_vol[...] = out

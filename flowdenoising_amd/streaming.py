@@ -37,18 +37,22 @@ def filter_streamed(vol, kernels, l, w, chunk_slices=None, use_of=True, border_m
     the GPU (None: as many as fit).  `workers` chunks are in flight at once, each on its own handle and
     stream, so that one chunk's host copies and transfers overlap another's kernels.
     `vol`: (Z, Y, X) array-like on the host; returns a new float32 array."""
+    from .operators import integer_semantics
     src = np.asarray(vol)
     if src.ndim != 3:
         raise ValueError(f"expected a (Z, Y, X) volume, got shape {src.shape}")
+    wrap = border_mode == _lib.BORDER_WRAP
+    params = _lib.SweepParams(int(l), int(w), OF_ITERS, OF_POLY_N, OF_POLY_SIGMA, int(border_mode), int(bool(chained)),
+                              int(bool(use_of)))
+    params = integer_semantics(src, params)             # an integer MRC keeps its dtype in the reference (seq:513)
+    if params.warp_mode == _lib.WARP_F64_PADDED:
+        mean = np.float32(params.pad64)
     if src.dtype != np.float32:
         src = src.astype(np.float32)
     if not src.flags["C_CONTIGUOUS"]:
         src = np.ascontiguousarray(src)
     if mean is None:
         mean = _lib.mean_host(src)                      # seq:420
-    wrap = border_mode == _lib.BORDER_WRAP
-    params = _lib.SweepParams(int(l), int(w), OF_ITERS, OF_POLY_N, OF_POLY_SIGMA, int(border_mode), int(bool(chained)),
-                              int(bool(use_of)))
     h = handle(device)
     free = None
     if chunk_slices is None:
@@ -170,7 +174,11 @@ def _passes(src, kernels, chunk_slices, free, mean, wrap, params, pool, worker_h
                     else:                                 # volume[:, :, g0:g0+cnt]: Z * Y rows of cnt floats -> (cnt, Z, Y)
                         h.h2d_2d(d_blk, cnt * 4, base + g0 * 4, X * 4, cnt * 4, Z * Y)
                         h.permute_dev(d_blk, dst, (cnt, H, W), (1, W * cnt, cnt))
-                h.sweep_stack_dev(d_stack, d_out, S, H, W, k, params)
+                pc = params
+                if params.warp_mode == _lib.WARP_F64_PADDED:      # which stack slices are pad slices (float64 mean there)
+                    pc = params.copy()
+                    pc.pad_lo, pc.pad_hi = runs[0][0], S + 2 * r - runs[0][0] - runs[0][2]
+                h.sweep_stack_dev(d_stack, d_out, S, H, W, k, pc)
                 obase = out.ctypes.data
                 if axis == 0:
                     h.d2h_2d(obase + s0 * HW * 4, S * HW * 4, d_out, S * HW * 4, S * HW * 4, 1)

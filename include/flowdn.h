@@ -50,7 +50,24 @@ typedef struct fdn_sweep_params {
     int chained;     /* 1: previous flow seeds the next (seq:97-98);
                         0: --recompute_flow, zero initial flow (par:89-114)     */
     int use_of;      /* 0: -n/--no_OF plain separable Gaussian (seq:426-431)    */
+    /* Integer volumes.  Both reference programs keep an integer MRC's dtype (seq:513, par:472), and what cv2.remap
+     * and numpy then do differs from the float32 case (all zero = float32 semantics):
+     *   FDN_WARP_F64_PADDED (seq): vol.mean() is a float64 (seq:420), so np.full makes the padded volume float64
+     *     (seq:88-89) in all three passes: cv2.remap weights its taps in double and does not round to float32, and
+     *     pad slices hold the float64 mean `pad64` (Farneback still sees float32 images: pad_value = (float)pad64);
+     *   FDN_WARP_ROUND_INT (par): the neighbour slices ARE integer images: cv2.remap's result is rounded half to
+     *     even and saturated to the type's range [round_lo, round_hi], and every pass's result is truncated toward
+     *     zero into the integer volume (par:131, par:287-289).
+     * The caller converts the volume to float32 (exact for 8/16-bit types) and says which it was. */
+    int warp_mode;   /* FDN_WARP_*                                              */
+    int pad_lo, pad_hi; /* fdn_sweep_stack_dev with FDN_WARP_F64_PADDED: how many leading / trailing stack slices are
+                        pad slices (the other entry points know where they padded and ignore these)            */
+    double pad64;    /* FDN_WARP_F64_PADDED: the float64 mean                    */
+    double round_lo, round_hi; /* FDN_WARP_ROUND_INT: e.g. -32768, 32767 for mode-1 MRC */
 } fdn_sweep_params;
+#define FDN_WARP_F32 0
+#define FDN_WARP_F64_PADDED 1
+#define FDN_WARP_ROUND_INT 2
 
 /* ---- lifetime ------------------------------------------------------------------ */
 /* Binds a handle to HIP device `device` and creates its stream.  Replaces the implicit

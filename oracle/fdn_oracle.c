@@ -922,6 +922,47 @@ static void neighbour(const float* vol, int Z, int Y, int X, int axis, int n, in
     else get_slice(vol, Z, Y, X, axis, q, out);
 }
 
+/* Integer-input semantics (seq:513 keeps an integer MRC's dtype, so seq:420's vol.mean() is a float64 and seq:88's
+ * np.full makes the PADDED volume float64 -- in all three passes, the mean being computed once): Farneback still
+ * converts its images to f32 (pad slices become f32(mean)), but cv2.remap of a CV_64F image weights the four taps in
+ * double (f32 table weights widened, products and sums in f64, no rounding to f32) and the pad slices hold the f64
+ * mean.  The HIP path does not implement this (it pads and remaps in f32); the oracle does, so that a test can
+ * bound the difference (tests/test_gpu_full.py::test_integer_input_semantics_bound). */
+static int g_f64_padded = 0;
+static double g_mean64 = 0.;
+FDO_EXPORT void fdo_set_f64_padded(int on, double mean64) { g_f64_padded = on; g_mean64 = mean64; }
+
+/* par on an integer MRC (par:472 keeps the dtype): the neighbour slices are integer images, so cv2.remap returns that type:
+ * remapBilinear<Cast<float, short>> = saturate_cast<short>(float) = cvRound (half to even), clamped to the type's range;
+ * and self.filtered_vol = np.zeros_like(vol) truncates every pass's float32 slices toward zero (par:131, par:287-289). */
+static int g_int_round = 0;
+static float g_int_lo = 0.f, g_int_hi = 0.f;
+FDO_EXPORT void fdo_set_int_round(int on, double lo, double hi) { g_int_round = on; g_int_lo = (float)lo; g_int_hi = (float)hi; }
+
+static void warp_slice_f64(const float* reference, int is_pad, const float* flow, double* dst, int H, int W)
+{
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            size_t i = ((size_t)y * W + x) * 2;
+            float mx = (float)((double)flow[i] + (double)x), my = (float)((double)flow[i + 1] + (double)y);
+            int sx = cv_round_f(mx * 32), sy = cv_round_f(my * 32);
+            int ax = sx & 31, ay = sy & 31;
+            int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);
+            float tx1 = ax * (1.f / 32), tx0 = 1.f - tx1;
+            float ty1 = ay * (1.f / 32), ty0 = 1.f - ty1;
+            float w0 = ty0 * tx0, w1 = ty0 * tx1, w2 = ty1 * tx0, w3 = ty1 * tx1;
+            int x0 = clampi(ix, 0, W - 1), x1 = clampi(ix + 1, 0, W - 1);
+            int y0 = clampi(iy, 0, H - 1), y1 = clampi(iy + 1, 0, H - 1);
+            double v0, v1, v2, v3;
+            if (is_pad) v0 = v1 = v2 = v3 = g_mean64;
+            else {
+                v0 = reference[(size_t)y0 * W + x0]; v1 = reference[(size_t)y0 * W + x1];
+                v2 = reference[(size_t)y1 * W + x0]; v3 = reference[(size_t)y1 * W + x1];
+            }
+            dst[(size_t)y * W + x] = v0 * (double)w0 + v1 * (double)w1 + v2 * (double)w2 + v3 * (double)w3;
+        }
+}
+
 /* Targets s0 <= s < s1 only (the other output slices are left untouched): used to time a
  * bounded sample of a large volume (bench.py cpu_baseline). */
 FDO_EXPORT void fdo_filter_axis_range(const float* vol, float* out, int Z, int Y, int X, int axis,
@@ -943,6 +984,7 @@ FDO_EXPORT void fdo_filter_axis_range(const float* vol, float* out, int Z, int Y
         float* warped = (float*)malloc(npx * sizeof(float));
         float* tmp = (float*)malloc(npx * sizeof(float));
         float* flow = (float*)malloc(npx * 2 * sizeof(float));
+        double* warped64 = g_f64_padded ? (double*)malloc(npx * sizeof(double)) : NULL;
 #pragma omp for schedule(static)
         for (int s = s0; s < s1; s++) {
             get_slice(vol, Z, Y, X, axis, s, target);
@@ -950,9 +992,15 @@ FDO_EXPORT void fdo_filter_axis_range(const float* vol, float* out, int Z, int Y
             if (!sp->use_of) { /* seq:184-185: taps in index order 0..K-1 */
                 for (int i = 0; i < K; i++) {
                     neighbour(vol, Z, Y, X, axis, n, s, i, K, mean, sp->border_mode, npx, ref);
+                    int q = s + i - K / 2;
+                    if (g_f64_padded && sp->border_mode == 0 && (q < 0 || q >= n)) {
+                        for (size_t j = 0; j < npx; j++) tmp[j] = (float)((double)tmp[j] + g_mean64 * kernel[i]);
+                        continue;
+                    }
                     for (size_t j = 0; j < npx; j++)
                         tmp[j] = (float)((double)tmp[j] + (double)ref[j] * kernel[i]);
                 }
+                if (g_int_round) for (size_t j = 0; j < npx; j++) { float v = truncf(tmp[j]); tmp[j] = v < g_int_lo ? g_int_lo : v > g_int_hi ? g_int_hi : v; }
                 put_slice(out, Z, Y, X, axis, s, tmp);
                 continue;
             }
@@ -966,15 +1014,27 @@ FDO_EXPORT void fdo_filter_axis_range(const float* vol, float* out, int Z, int Y
                     neighbour(vol, Z, Y, X, axis, n, s, i, K, mean, sp->border_mode, npx, ref);
                     if (!sp->chained) memset(flow, 0, npx * 2 * sizeof(float));
                     fdo_farneback(target, ref, flow, H, W, &fb);   /* prev=target, next=reference (seq:62) */
+                    if (g_f64_padded) {
+                        int q = s + i - K / 2;
+                        warp_slice_f64(ref, sp->border_mode == 0 && (q < 0 || q >= n), flow, warped64, H, W);
+                        for (size_t j = 0; j < npx; j++) tmp[j] = (float)((double)tmp[j] + warped64[j] * kernel[i]);
+                        continue;
+                    }
                     fdo_warp_slice(ref, flow, warped, H, W);       /* seq:106 */
+                    if (g_int_round)
+                        for (size_t j = 0; j < npx; j++) {
+                            float v = rintf(warped[j]);
+                            warped[j] = v < g_int_lo ? g_int_lo : v > g_int_hi ? g_int_hi : v;
+                        }
                     /* seq:107: f32 array * f64 scalar is f64 under numpy>=2; += stores f32 */
                     for (size_t j = 0; j < npx; j++)
                         tmp[j] = (float)((double)tmp[j] + (double)warped[j] * kernel[i]);
                 }
             }
+            if (g_int_round) for (size_t j = 0; j < npx; j++) { float v = truncf(tmp[j]); tmp[j] = v < g_int_lo ? g_int_lo : v > g_int_hi ? g_int_hi : v; }
             put_slice(out, Z, Y, X, axis, s, tmp);
         }
-        free(target); free(ref); free(warped); free(tmp); free(flow);
+        free(target); free(ref); free(warped); free(tmp); free(flow); free(warped64);
     }
 }
 

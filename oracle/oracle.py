@@ -66,6 +66,35 @@ def set_fma(on):
     lib().fdo_set_fma(ctypes.c_int(int(bool(on))))
 
 
+def OF_filter_integer_input(vol, kernel, l, w, nthreads=1, use_of=True):
+    """seq:419-424 on an INTEGER volume (an int8/int16/uint16 MRC keeps its dtype, seq:513): vol.mean() is then a float64,
+    seq:88's padded volume is float64 in all three passes, cv2.remap weights in double and the pad slices hold the f64
+    mean (fdn_oracle.c, fdo_set_f64_padded).  The HIP path converts such input to float32 instead; this
+    restatement exists to bound that difference."""
+    vol = np.asarray(vol)
+    assert np.issubdtype(vol.dtype, np.integer)
+    mean64 = float(vol.mean())
+    lib().fdo_set_f64_padded(ctypes.c_int(1), ctypes.c_double(mean64))
+    try:
+        return _filter_3d(vol.astype(np.float32), kernel, l, w, use_of, 0, True, BOX_RUNNING, nthreads, mean=np.float32(mean64))
+    finally:
+        lib().fdo_set_f64_padded(ctypes.c_int(0), ctypes.c_double(0.0))
+
+
+def filter_par_integer_input(vol, kernel, l, w, nthreads=1, use_of=True, chained=True):
+    """par:285-290 on an INTEGER volume (par:472 keeps an MRC's dtype): wrap-around neighbours that are integer images --
+    cv2.remap rounds half to even and saturates -- and every pass truncated into the integer volume (fdn_oracle.c,
+    fdo_set_int_round).  Returns float32 holding the integer values (all three passes; the reference loses its X pass)."""
+    vol = np.asarray(vol)
+    assert vol.dtype in (np.int16, np.uint16) or (not use_of and np.issubdtype(vol.dtype, np.integer))
+    info = np.iinfo(vol.dtype)
+    lib().fdo_set_int_round(ctypes.c_int(1), ctypes.c_double(info.min), ctypes.c_double(info.max))
+    try:
+        return _filter_3d(vol.astype(np.float32), kernel, l, w, use_of, 1, chained, BOX_RUNNING, nthreads, mean=np.float32(0))
+    finally:
+        lib().fdo_set_int_round(ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0))
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 

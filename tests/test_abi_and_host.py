@@ -176,3 +176,20 @@ def test_synth_slabs_tile_the_volume():
     full = make_volume((12, 20, 24), seed=9, noise=0.0)
     parts = [make_volume((12, 20, 24), seed=9, noise=0.0, z0=z0, zlen=4) for z0 in (0, 4, 8)]
     np.testing.assert_allclose(np.concatenate(parts), full, rtol=1e-6)
+
+
+def test_sweep_params_layout_matches_the_header(tmp_path):
+    """ctypes' SweepParams against include/flowdn.h's struct as gcc lays it out: size and every field offset."""
+    import ctypes
+    import subprocess
+    from flowdenoising_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = [f[0] for f in _lib.SweepParams._fields_]
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "flowdn.h"\nint main(void) { printf("%zu", sizeof(fdn_sweep_params));\n'
+           + "".join(f'printf(" %zu", offsetof(fdn_sweep_params, {n}));\n' for n in names) + "return 0; }\n")
+    (tmp_path / "l.c").write_text(src)
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), "-o", str(tmp_path / "l"), str(tmp_path / "l.c")])
+    got = [int(v) for v in subprocess.check_output([str(tmp_path / "l")]).split()]
+    assert got[0] == ctypes.sizeof(_lib.SweepParams)
+    assert got[1:] == [getattr(_lib.SweepParams, n).offset for n in names]
+    assert (_lib.WARP_F32, _lib.WARP_F64_PADDED, _lib.WARP_ROUND_INT) == (0, 1, 2)

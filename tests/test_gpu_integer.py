@@ -1,0 +1,148 @@
+"""Integer volumes.  Both reference programs keep an integer MRC's dtype (seq:513 / par:472 `vol = vol_MRC.data`), and what
+numpy and cv2 then do is not the float32 computation:
+  seq: vol.mean() is a float64 (seq:420) -> np.full makes the padded volume float64 (seq:88-89), in all three passes ->
+       cv2.remap weights its taps in double and does not round to float32; pad slices hold the float64 mean;
+  par: the neighbour slices are integer images -> cv2.remap rounds half to even and saturates; every pass is
+       truncated into the integer volume (par:131, 287-289).
+These differ from the float32 path by far more than a rounding (1.5e-4 of the range on the volume below: the next
+pass's flows amplify a last-bit difference), so the library implements both (include/flowdn.h FDN_WARP_*) and the
+oracle restates both (oracle.OF_filter_integer_input, oracle.filter_par_integer_input).  As for the float32 path the
+oracle's reading of OpenCV is unpinned (no cv2 here)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _int_vol(shape, seed, dtype=np.int16, signed_shift=0):
+    from flowdenoising_amd.synth import make_volume
+    v = make_volume(shape, seed=seed, amplitude=100.0)
+    lo, hi = float(v.min()), float(v.max())
+    return (np.round((v - lo) / (hi - lo) * 4095) - signed_shift).astype(dtype)
+
+
+@pytest.mark.parametrize("dtype,shift", [(np.int16, 2000), (np.uint16, 0), (np.int8, None)])
+@pytest.mark.parametrize("l,w", [(0, 5), (2, 15), (1, 9)])
+def test_seq_semantics_float64_padded_volume(fdn, oracle, dtype, shift, l, w):
+    if shift is None:       # int8: a small range
+        vol = (_int_vol((10, 48, 56), 11) // 20 - 100).astype(np.int8)
+    else:
+        vol = _int_vol((10, 48, 56), 11, dtype, shift)
+    ks = [fdn.get_gaussian_kernel(s) for s in (1.0, 1.0, 0.5)]
+    want = oracle.OF_filter_integer_input(vol, ks, l, w, nthreads=8)
+    got = fdn.OF_filter(vol, ks, l, w)
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+    # and it is NOT what the float32 path computes from the same numbers
+    as_f32 = fdn.OF_filter(vol.astype(np.float32), ks, l, w)
+    assert not np.array_equal(as_f32, got)
+    assert np.array_equal(as_f32, oracle.OF_filter(vol.astype(np.float32), ks, l, w, nthreads=8))
+
+
+def test_seq_semantics_on_every_path_and_no_of(fdn, oracle):
+    from flowdenoising_amd.operators import handle
+    vol = _int_vol((9, 40, 70), 12, np.int16, 1000)
+    ks = [fdn.get_gaussian_kernel(s) for s in (1.0, 0.5, 1.0)]
+    want = oracle.OF_filter_integer_input(vol, ks, 0, 5, nthreads=8)
+    h = handle()
+    try:
+        for path in (0, 1, 2):          # 3-iteration kernel, per-stage kernels, one-iteration kernel
+            h.set_option("path", path)
+            assert np.array_equal(fdn.OF_filter(vol, ks, 0, 5), want), path
+    finally:
+        h.set_option("path", 0)
+    assert np.array_equal(fdn.no_OF_filter(vol, ks), oracle.OF_filter_integer_input(vol, ks, 0, 5, use_of=False))
+    # a single pass given a float64 mean is a float64 padded volume too (np.full takes the dtype of `mean`, seq:88)
+    f32 = vol.astype(np.float32)
+    m64 = float(vol.mean())
+    one = fdn.OF_filter_along_Z(f32, ks[0], 0, 5, m64)
+    assert not np.array_equal(one, fdn.OF_filter_along_Z(f32, ks[0], 0, 5, np.float32(m64)))
+
+
+def test_seq_semantics_chunked_and_streamed(fdn, oracle):
+    """The pad slices of every chunk are found again when a workspace limit cuts the passes, and in the out-of-core mode."""
+    from flowdenoising_amd import streaming
+    from flowdenoising_amd.operators import handle
+    vol = _int_vol((13, 64, 72), 13, np.uint16)
+    ks = [fdn.get_gaussian_kernel(s) for s in (1.5, 1.0, 1.0)]
+    want = fdn.OF_filter(vol, ks, 1, 5)
+    assert np.array_equal(want, oracle.OF_filter_integer_input(vol, ks, 1, 5, nthreads=8))
+    h = handle()
+    try:
+        h.set_workspace_limit(6 << 20)
+        assert np.array_equal(fdn.OF_filter(vol, ks, 1, 5), want)
+    finally:
+        h.set_workspace_limit(0)
+    assert np.array_equal(streaming.OF_filter_streamed(vol, ks, 1, 5, 4), want)
+    assert np.array_equal(streaming.no_OF_filter_streamed(vol, ks, 3), fdn.no_OF_filter(vol, ks))
+
+
+def test_seq_semantics_slab_engine(fdn, oracle):
+    torch = pytest.importorskip("torch")
+    from flowdenoising_amd import _lib
+    from flowdenoising_amd.distributed import SlabEngine, SlabPlan
+    from flowdenoising_amd.operators import handle, integer_semantics, _params
+    vol = _int_vol((9, 36, 40), 14, np.int16, 500)
+    ks = [fdn.get_gaussian_kernel(s) for s in (1.0, 0.5, 0.5)]
+    params = integer_semantics(vol, _params(0, 5))
+    assert params.warp_mode == _lib.WARP_F64_PADDED and params.pad64 == float(vol.mean())
+    h = handle()
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        eng = SlabEngine(SlabPlan(vol.shape, 1, 0), h, None)
+        out = eng.filter_3d(torch.from_numpy(vol.astype(np.float32)).cuda(), ks, params, mean=np.float32(params.pad64)).cpu().numpy()
+    finally:
+        h.reset_stream()
+    assert np.array_equal(out, oracle.OF_filter_integer_input(vol, ks, 0, 5, nthreads=8))
+
+
+@pytest.mark.parametrize("dtype,shift", [(np.int16, 2000), (np.uint16, 0)])
+@pytest.mark.parametrize("l,w,chained", [(0, 5, True), (3, 15, True), (1, 7, False)])
+def test_par_semantics_integer_images(fdn, oracle, dtype, shift, l, w, chained):
+    vol = _int_vol((8, 44, 52), 15, dtype, shift)
+    ks = [fdn.get_gaussian_kernel(s) for s in (1.0, 0.5, 1.0)]
+    v = vol.copy()
+    fd = fdn.FlowDenoising(4, v, l, w, fdn.get_flow_with_prev_flow if chained else fdn.get_flow_without_prev_flow, fdn.warp_slice)
+    assert fd.filter(ks) is None
+    want = oracle.filter_par_integer_input(vol, ks, l, w, nthreads=8, chained=chained)
+    assert v.dtype == dtype and np.array_equal(v, want.astype(dtype)) and np.array_equal(fd.filtered_vol, v)
+    assert np.array_equal(want, np.trunc(want))            # integers all along
+
+
+def test_par_semantics_no_of_and_unsupported_types(fdn, oracle):
+    vol = _int_vol((8, 30, 34), 16, np.int16, 100)
+    ks = [fdn.get_gaussian_kernel(0.5)] * 3
+    v = vol.copy()
+    fdn.GaussianDenoising(2, v).filter(ks)
+    assert np.array_equal(v, oracle.filter_par_integer_input(vol, ks, 0, 5, use_of=False).astype(np.int16))
+    with pytest.raises(ValueError):         # cv2.remap has no CV_8S path: the reference fails there too
+        fdn.FlowDenoising(1, (vol // 40).astype(np.int8), 0, 5).filter(ks)
+    with pytest.raises(ValueError):
+        fdn.OF_filter(vol.astype(np.int32), ks, 0, 5)
+
+
+def test_cli_on_an_int16_mrc(fdn, oracle, tmp_path):
+    """flowdenoising.py on a mode-1 MRC: seq semantics by default, par's with --compat par; float32 MRC out either way."""
+    from flowdenoising_amd import io as fio
+    vol = _int_vol((9, 40, 44), 17, np.int16, 1500)
+    hdr = bytearray(1024)                 # a mode-1 (int16) MRC2014 header
+    hdr[0:16] = np.array([vol.shape[2], vol.shape[1], vol.shape[0], 1], "<i4").tobytes()
+    hdr[208:212] = b"MAP "
+    hdr[212:216] = bytes([0x44, 0x44, 0, 0])
+    open(str(tmp_path / "in.mrc"), "wb").write(bytes(hdr) + vol.astype("<i2").tobytes())
+    assert fio.read_mrc(str(tmp_path / "in.mrc")).dtype == np.int16
+    ks = [oracle.get_gaussian_kernel(s) for s in (1.0, 0.5, 1.0)]
+    exe = [sys.executable, os.path.join(ROOT, "flowdenoising.py"), "-i", str(tmp_path / "in.mrc"), "-s", "1.0", "0.5", "1.0"]
+    r = subprocess.run(exe + ["-o", str(tmp_path / "a.mrc")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(fio.read_mrc(str(tmp_path / "a.mrc")), oracle.OF_filter_integer_input(vol, ks, 0, 5, nthreads=8))
+    r = subprocess.run(exe + ["-o", str(tmp_path / "b.mrc"), "--compat", "par", "-l", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(fio.read_mrc(str(tmp_path / "b.mrc")), oracle.filter_par_integer_input(vol, ks, 1, 5, nthreads=8))
+    r = subprocess.run(exe + ["-o", str(tmp_path / "c.mrc"), "--chunk_slices", "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(fio.read_mrc(str(tmp_path / "c.mrc")), fio.read_mrc(str(tmp_path / "a.mrc")))

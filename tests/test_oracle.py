@@ -211,3 +211,39 @@ def test_threads_do_not_change_results(oracle):
     a = oracle.filter_along_axis(vol, 1, k, 0, 5, vol.mean(), nthreads=1)
     b = oracle.filter_along_axis(vol, 1, k, 0, 5, vol.mean(), nthreads=4)
     assert np.array_equal(a, b)
+
+
+def _int_volume(shape, seed):
+    from flowdenoising_amd.synth import make_volume
+    v = make_volume(shape, seed=seed, amplitude=100.0)
+    lo, hi = float(v.min()), float(v.max())
+    return np.round((v - lo) / (hi - lo) * 4095).astype(np.int16)
+
+
+def test_integer_volume_semantics_are_not_the_float32_ones(oracle):
+    """seq on an integer MRC pads and remaps in float64 (seq:420, seq:88-89): against the same numbers converted to
+    float32 first, single results move by 1e-4 of the range -- a last-bit difference of one pass is amplified by the
+    next pass's flows -- which is why the HIP library implements the integer semantics instead of converting
+    (tests/test_gpu_integer.py).  Without optical flow the two differ by float rounding only."""
+    vi = _int_volume((10, 48, 56), 11)
+    ks = [oracle.get_gaussian_kernel(s) for s in (1.0, 1.0, 0.5)]
+    a = oracle.OF_filter(vi.astype(np.float32), ks, 0, 5, nthreads=8)
+    b = oracle.OF_filter_integer_input(vi, ks, 0, 5, nthreads=8)
+    d = np.abs(a - b).max() / np.abs(b).max()
+    assert 1e-6 < d < 1e-2
+    a = oracle.no_OF_filter(vi.astype(np.float32), ks)
+    b = oracle.OF_filter_integer_input(vi, ks, 0, 5, use_of=False)
+    assert np.abs(a - b).max() / np.abs(b).max() < 5e-7
+
+
+def test_integer_volume_known_answers(oracle):
+    """Constant integer volume: seq gives c * sum(taps) per pass (the float64 pad is c too); par's wrap-around passes
+    leave every voxel at c exactly (remap of a constant integer image is that integer, the taps sum to 1 +- 1e-16 and
+    the truncation must not drop it to c - 1 ... which it does when the float32 sum lands just below c: the reference
+    has that bias, and the restatement keeps it)."""
+    vol = np.full((5, 34, 36), 1000, np.int16)
+    ks = [oracle.get_gaussian_kernel(0.5)] * 3
+    out = oracle.OF_filter_integer_input(vol, ks, 0, 5)
+    np.testing.assert_allclose(out, 1000.0, rtol=1e-6)
+    par = oracle.filter_par_integer_input(vol, ks, 0, 5)
+    assert np.array_equal(par, np.trunc(par)) and np.all((par == 1000) | (par == 999))
