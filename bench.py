@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--amplitude", type=float, default=100.0)
     ap.add_argument("--levels", type=int, default=0, help="pyramid levels (-l); configs[4] uses 3")
     ap.add_argument("--winsize", type=int, default=5, help="Farneback window (-w); configs[4] uses 15")
+    ap.add_argument("--integer", choices=("", "seq", "par"), default="", help="time the integer-volume semantics instead (not the headline): "
+                    "seq = float64 padded volume, par = integer images; N = 1 only")
     ap.add_argument("--path", type=int, default=0, help="fdn_set_option path: 0 auto, 1 staged, 2 per-iteration kernels")
     ap.add_argument("--cpu-targets", type=int, default=0, help="target slices of the CPU sample (0 = four per core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -272,6 +274,8 @@ def main():
     kernels = [kernel if c in a.axes else None for c in "zyx"]
     naxes = sum(k is not None for k in kernels)
     params = _lib.SweepParams(a.levels, a.winsize, 3, 5, 1.2, _lib.BORDER_MEAN_PAD, 1, 1)
+    if a.integer == "par":
+        params.border_mode, params.warp_mode, params.round_lo, params.round_hi = _lib.BORDER_WRAP, _lib.WARP_ROUND_INT, -32768.0, 32767.0
 
     h = _lib.Handle(local_rank)
     h.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -283,8 +287,13 @@ def main():
         vol = synth.make_volume(shape, seed=1234 + 3, amplitude=a.amplitude, xp=torch, device=dev)
         out = torch.empty_like(vol)
 
+        if a.integer:
+            vol = torch.round(vol)                               # integer values, as an int16 MRC would hold
+
         def step():
             mean = h.mean_dev(vol.data_ptr(), vol.numel())       # seq:420
+            if a.integer == "seq":
+                params.warp_mode, params.pad64 = _lib.WARP_F64_PADDED, float(mean)
             h.filter_3d_dev(vol.data_ptr(), out.data_ptr(), shape, kernels, mean, params)
             return mean
         parallelism = "1 GPU"
@@ -364,7 +373,9 @@ def main():
             res["kernel_ms_per_step"] = {k: round(v[0] / a.steps, 2) for k, v in timers.items() if v[1]}
         if phases:
             res["phase_ms_per_step_per_rank"] = phases
-        if world == 1 and not a.no_check:
+        if a.integer:
+            res["config"]["workload"] += f"; INTEGER-VOLUME SEMANTICS ({a.integer}) -- not the headline configuration"
+        if world == 1 and not a.no_check and not a.integer:
             h.enable_timers(False)
             res["checked"] = check_output(h, vol, out, shape, kernels, params, mean)
             h.enable_timers(True)
