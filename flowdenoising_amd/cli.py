@@ -116,6 +116,8 @@ def _run_sharded(args, shape, kernels, l, w):
         logging.warning(f"--gpus {world} on a node with {torch.cuda.device_count()} GPU(s): the ranks share GPU 0")
     plan = SlabPlan(shape, world, rank)
     raw = fio.read_slab(args.input, plan.z0, plan.z0 + plan.zlen)
+    if not fio.is_mrc_input(args.input):
+        raw = raw.astype(np.float32)                # seq:517: only an MRC keeps an integer dtype
     border = _lib.BORDER_WRAP if args.compat == "par" else _lib.BORDER_MEAN_PAD
     params = integer_semantics(raw, _params(l, w, use_of=not args.no_OF, border_mode=border, chained=not args.recompute_flow))
     mean = None
@@ -189,6 +191,8 @@ def main(argv=None):
         vol = None
     else:
         vol = fio.read_volume(args.input, mmap=args.memory_map)
+        if not fio.is_mrc_input(args.input):
+            vol = vol.astype(np.float32)            # seq:517, par:475: a TIFF is float32 from here on; an MRC keeps its dtype (seq:513)
         shape, dtype = vol.shape, vol.dtype
     logging.info(f"read \"{args.input}\" in {time.perf_counter() - t0} seconds")
     logging.info(f"shape of the input volume (Z, Y, X) = {shape}")
