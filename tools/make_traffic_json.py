@@ -3,7 +3,7 @@
 reads for roofline.traffic / roofline.limiter.  It is stamped with the hash of the kernel sources, the commit and
 the workload it was taken on; bench.py ignores it (traffic = null, loud warning) when any of them differs.
 
-usage: make_traffic_json.py <kernel substring> <out.json> <commit> [pmc glob]"""
+usage: make_traffic_json.py <kernel substring> <out.json> <commit> [pmc glob] [levels winsize]"""
 import collections
 import csv
 import glob
@@ -25,6 +25,7 @@ for f in sorted(glob.glob(pat, recursive=True)):
 mean = {k: sum(v) / len(v) for k, v in acc.items()}
 if "FETCH_SIZE" not in mean or "WRITE_SIZE" not in mean:
     sys.exit(f"no FETCH_SIZE/WRITE_SIZE rows for {kern} under {pat}")
+levels, winsize = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (0, 5)
 shape = [512, 1024, 1024]
 px = shape[0] * shape[1] * shape[2]
 # FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE x 2 is the guide's gfx950 correction (128-B fabric reads tallied at 64 B)
@@ -33,9 +34,10 @@ res = {
     "kernel": kern,
     "kernel_source_sha": bench.kernel_source_hash(),
     "commit": commit,
-    "command": "rocprofv3 --pmc <set> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-timers --no-check "
+    "command": "rocprofv3 --pmc <set> -- python bench.py" + (f" --levels {levels} --winsize {winsize}" if (levels, winsize) != (0, 5) else "")
+               + " --steps 1 --warmup 0 --no-cpu-baseline --no-timers --no-check "
                "(separate passes per counter set, tools/profile_round.sh)",
-    "workload": {"shape": shape, "winsize": 5, "levels": 0, "sigma": 2.0, "axes": "zyx"},
+    "workload": {"shape": shape, "winsize": winsize, "levels": levels, "sigma": 2.0, "axes": "zyx"},
     "launches_averaged": len(acc["FETCH_SIZE"]),
     "fetch_size_kib_per_launch": mean["FETCH_SIZE"], "write_size_kib_per_launch": mean["WRITE_SIZE"],
     "correction": "FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM section; re-checked on known byte counts by "

@@ -1,4 +1,5 @@
 # PMC passes + kernel stats of the wide-window path (bench.py --levels 3 --winsize 15); run through gpurun from the repo root.
+# usage: bash tools/profile_w15.sh <commit>   (results in gpurun_out/w15_*; copy into profiles/r02_w15_*)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out; rm -rf gpurun_out/w15_trace gpurun_out/w15_pmc*
 B="python3 bench.py --levels 3 --winsize 15 --steps 1 --warmup 0 --no-cpu-baseline --no-timers --no-check"
@@ -11,3 +12,4 @@ done
 python3 tools/pmc_summary.py "gpurun_out/w15_pmc*/**/*_counter_collection.csv" "k_farneback_iter<7, 1, true>" > gpurun_out/w15_pmc_summary.txt
 python3 tools/pmc_summary.py "gpurun_out/w15_pmc*/**/*_counter_collection.csv" "k_farneback_iter<7, 1, false>" >> gpurun_out/w15_pmc_summary.txt
 cat gpurun_out/w15_pmc_summary.txt
+python3 tools/make_traffic_json.py "k_farneback_iter<7, 1, true>" gpurun_out/w15_traffic.json ${1:-unknown} "gpurun_out/w15_pmc*/**/*_counter_collection.csv" 3 15
