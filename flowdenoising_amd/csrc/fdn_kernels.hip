@@ -522,7 +522,11 @@ void launch_sweep_side(const float* stack, const float* flows, float* acc, PairB
         SweepWeights sw;
         for (int i = 0; i < n; i++) sw.w[i] = weights[s0 + i];
         const float* fl = flows + (size_t)s0 * step_stride;
-        if (wm.kind == 1) hipLaunchKernelGGL((k_sweep_side<8, 1>), grid, dim3(256), 0, st, stack, fl, acc, pb, n, first_step + s0, H, W, sw, wm);
+        if (n == 1) {   // one step at a time (the integer-volume modes behind the Farneback kernels): no unrolled group to fill
+            if (wm.kind == 1) hipLaunchKernelGGL((k_sweep_side<1, 1>), grid, dim3(256), 0, st, stack, fl, acc, pb, n, first_step + s0, H, W, sw, wm);
+            else if (wm.kind == 2) hipLaunchKernelGGL((k_sweep_side<1, 2>), grid, dim3(256), 0, st, stack, fl, acc, pb, n, first_step + s0, H, W, sw, wm);
+            else hipLaunchKernelGGL((k_sweep_side<1, 0>), grid, dim3(256), 0, st, stack, fl, acc, pb, n, first_step + s0, H, W, sw, wm);
+        } else if (wm.kind == 1) hipLaunchKernelGGL((k_sweep_side<8, 1>), grid, dim3(256), 0, st, stack, fl, acc, pb, n, first_step + s0, H, W, sw, wm);
         else if (wm.kind == 2) hipLaunchKernelGGL((k_sweep_side<8, 2>), grid, dim3(256), 0, st, stack, fl, acc, pb, n, first_step + s0, H, W, sw, wm);
         else hipLaunchKernelGGL((k_sweep_side<8, 0>), grid, dim3(256), 0, st, stack, fl, acc, pb, n, first_step + s0, H, W, sw, wm);
     }
