@@ -963,6 +963,25 @@ static void warp_slice_f64(const float* reference, int is_pad, const float* flow
         }
 }
 
+/* cv2.remap(INTER_LINEAR, BORDER_REPLICATE) of a CV_64F image with an explicit map (what the tests' cv2 stand-in needs) */
+FDO_EXPORT void fdo_remap_linear_replicate_f64(const double* src, int H, int W, const float* mapxy, double* dst)
+{
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const float* mp = mapxy + ((size_t)y * W + x) * 2;
+            int sx = cv_round_f(mp[0] * 32), sy = cv_round_f(mp[1] * 32);
+            int ax = sx & 31, ay = sy & 31;
+            int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);
+            float tx1 = ax * (1.f / 32), tx0 = 1.f - tx1;
+            float ty1 = ay * (1.f / 32), ty0 = 1.f - ty1;
+            float w0 = ty0 * tx0, w1 = ty0 * tx1, w2 = ty1 * tx0, w3 = ty1 * tx1;
+            int x0 = clampi(ix, 0, W - 1), x1 = clampi(ix + 1, 0, W - 1);
+            int y0 = clampi(iy, 0, H - 1), y1 = clampi(iy + 1, 0, H - 1);
+            dst[(size_t)y * W + x] = src[(size_t)y0 * W + x0] * (double)w0 + src[(size_t)y0 * W + x1] * (double)w1
+                                   + src[(size_t)y1 * W + x0] * (double)w2 + src[(size_t)y1 * W + x1] * (double)w3;
+        }
+}
+
 /* Targets s0 <= s < s1 only (the other output slices are left untouched): used to time a
  * bounded sample of a large volume (bench.py cpu_baseline). */
 FDO_EXPORT void fdo_filter_axis_range(const float* vol, float* out, int Z, int Y, int X, int axis,

@@ -148,6 +148,26 @@ def remap(src, map_xy):
     return dst
 
 
+def remap_any(src, map_xy):
+    """cv2.remap(src, map, None, INTER_LINEAR, BORDER_REPLICATE) for the image depths the reference can meet: float32;
+    float64 (remapBilinear<Cast<double, double>>: weights widened, arithmetic in double); int16 / uint16 (Cast<float, T>:
+    float arithmetic, then saturate_cast = round half to even, clamped).  Returns an array of src's dtype, like cv2."""
+    src = np.asarray(src)
+    map_xy = _f32(map_xy)
+    H, W = src.shape
+    if src.dtype == np.float64:
+        s64 = np.ascontiguousarray(src)
+        dst = np.empty((H, W), np.float64)
+        lib().fdo_remap_linear_replicate_f64(_p(s64), ctypes.c_int(H), ctypes.c_int(W), _p(map_xy), _p(dst))
+        return dst
+    if src.dtype in (np.int16, np.uint16):
+        info = np.iinfo(src.dtype)
+        return np.clip(np.rint(remap(src.astype(np.float32), map_xy)), info.min, info.max).astype(src.dtype)
+    if src.dtype != np.float32:
+        raise TypeError(f"cv2.remap: unsupported depth {src.dtype} in this restatement")
+    return remap(src, map_xy)
+
+
 def warp_slice(reference, flow):
     """seq:51-57."""
     reference = _f32(reference)

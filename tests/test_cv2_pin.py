@@ -87,6 +87,64 @@ def cv2_of_filter(cv2, vol, kernels, l, w):
     return cur
 
 
+def numpy_seq_sweep(cv2, vol, kernels, l, w):
+    """seq's sweep with NO casts of this harness's own: the dtypes are whatever numpy and cv2 make of the volume's dtype,
+    as in the reference (seq:86-89 np.zeros_like(...).astype(float32), np.full(fill_value=mean), in-place += of seq:107,
+    seq:420 mean once for all passes).  For a float32 volume this is cv2_of_filter; for an integer volume the padded
+    volume is float64 and cv2.remap runs on CV_64F."""
+    mean = vol.mean()
+    cur = vol
+    for axis, k in enumerate(kernels):
+        if k is None:
+            continue
+        K = k.size
+        moved = np.moveaxis(cur, axis, 0)
+        n = moved.shape[0]
+        filtered = np.zeros_like(moved).astype(np.float32)
+        padded = np.full(shape=(n + K,) + moved.shape[1:], fill_value=mean)
+        padded[K // 2:n + K // 2] = moved
+        for s in range(n):
+            tmp = np.zeros_like(moved[s]).astype(np.float32)
+            prev_flow = np.zeros(moved.shape[1:] + (2,), dtype=np.float32)
+            for i in range(K // 2 - 1, -1, -1):
+                prev_flow = cv2_flow(cv2, np.ascontiguousarray(moved[s]), np.ascontiguousarray(padded[s + i]), l, w, prev_flow)
+                tmp += cv2_warp(cv2, np.ascontiguousarray(padded[s + i]), prev_flow) * k[i]
+            tmp += moved[s] * k[K // 2]
+            prev_flow = np.zeros(moved.shape[1:] + (2,), dtype=np.float32)
+            for i in range(K // 2 + 1, K):
+                prev_flow = cv2_flow(cv2, np.ascontiguousarray(moved[s]), np.ascontiguousarray(padded[s + i]), l, w, prev_flow)
+                tmp += cv2_warp(cv2, np.ascontiguousarray(padded[s + i]), prev_flow) * k[i]
+            filtered[s] = tmp
+        cur = np.ascontiguousarray(np.moveaxis(filtered, 0, axis))
+    return cur
+
+
+def numpy_par_sweep(cv2, vol, kernels, l, w):
+    """par's passes (par:306-373, 285-290) with numpy's own dtype propagation: wrap-around neighbours taken from the volume
+    in ITS dtype, filtered_vol = np.zeros_like(vol), vol[...] = filtered_vol after each pass (all three kept, unlike par)."""
+    vol = vol.copy()
+    for axis, k in enumerate(kernels):
+        if k is None:
+            continue
+        K, ks2 = k.size, k.size // 2
+        filtered_vol = np.zeros_like(vol)
+        moved, fmoved = np.moveaxis(vol, axis, 0), np.moveaxis(filtered_vol, axis, 0)
+        n = moved.shape[0]
+        for s in range(n):
+            tmp = np.zeros_like(moved[s]).astype(np.float32)
+            for side in (range(ks2 - 1, -1, -1), range(ks2 + 1, K)):
+                if side.start > ks2:
+                    tmp += moved[s] * k[ks2]
+                prev_flow = np.zeros(moved.shape[1:] + (2,), dtype=np.float32)
+                for i in side:
+                    ref = np.ascontiguousarray(moved[(s + i - ks2) % n])
+                    prev_flow = cv2_flow(cv2, np.ascontiguousarray(moved[s]), ref, l, w, prev_flow)
+                    tmp += cv2_warp(cv2, ref, prev_flow) * k[i]
+            fmoved[s] = tmp
+        vol[...] = filtered_vol
+    return vol
+
+
 def _flow_err(got, want):
     return float(np.abs(got - want).max() / max(np.abs(want).max(), 1.0))
 
@@ -174,6 +232,60 @@ def test_harness_sweep_is_seq_shaped(oracle):
     vol = make_volume((7, 34, 38), seed=3, amplitude=100.0)
     ks = [oracle.get_gaussian_kernel(1.0), oracle.get_gaussian_kernel(0.5), None]
     assert np.array_equal(cv2_of_filter(StandIn, vol, ks, 0, 5), oracle.OF_filter(vol, ks, 0, 5))
+
+
+class OracleCv2:
+    """cv2 stand-in on the oracle, dispatching on the image depth like cv2 does (convertTo(CV_32F) inside Farneback;
+    remap per depth)."""
+    OPTFLOW_USE_INITIAL_FLOW, INTER_LINEAR, BORDER_REPLICATE = 4, 1, 1
+
+    @staticmethod
+    def calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags):
+        from oracle import oracle
+        return oracle.calcOpticalFlowFarneback(np.asarray(prev, np.float32), np.asarray(next, np.float32), flow, pyr_scale,
+                                               levels, winsize, iterations, poly_n, poly_sigma, flags)
+
+    @staticmethod
+    def remap(src, m, _, interpolation, borderMode):
+        from oracle import oracle
+        return oracle.remap_any(src, m)
+
+
+def _int16_volume(shape, seed):
+    from flowdenoising_amd.synth import make_volume
+    v = make_volume(shape, seed=seed, amplitude=100.0)
+    lo, hi = float(v.min()), float(v.max())
+    return (np.round((v - lo) / (hi - lo) * 4095) - 1000).astype(np.int16)
+
+
+def test_numpy_dtype_propagation_of_integer_volumes(oracle):
+    """The NUMPY half of the integer-volume semantics, checked with real numpy: sweeps written like the reference's, with
+    no casts of their own, on the cv2 stand-in must give the oracle's integer restatements bit for bit -- np.full's dtype
+    (float64 padded volume), the in-place += into float32, the truncating store into an integer volume.  What stays
+    unpinned is cv2's side (remap on CV_64F / CV_16S), restated in oracle.remap_any."""
+    vi = _int16_volume((7, 34, 38), 21)
+    ks = [oracle.get_gaussian_kernel(1.0), oracle.get_gaussian_kernel(0.5), oracle.get_gaussian_kernel(0.5)]
+    assert np.array_equal(numpy_seq_sweep(OracleCv2, vi, ks, 0, 5), oracle.OF_filter_integer_input(vi, ks, 0, 5))
+    vf = vi.astype(np.float32)
+    assert np.array_equal(numpy_seq_sweep(OracleCv2, vf, ks, 0, 5), oracle.OF_filter(vf, ks, 0, 5))
+    got = numpy_par_sweep(OracleCv2, vi, ks, 0, 5)
+    assert got.dtype == np.int16 and np.array_equal(got, oracle.filter_par_integer_input(vi, ks, 0, 5).astype(np.int16))
+    assert np.array_equal(numpy_par_sweep(OracleCv2, vf, ks, 0, 5), oracle.OF_filter(vf, ks, 0, 5, border_mode=1))
+
+
+def test_integer_volumes_against_cv2(oracle):
+    """With real cv2: the same sweeps pin the integer semantics (remap on CV_64F and CV_16S, Farneback fed mixed depths)."""
+    cv2 = pytest.importorskip("cv2")
+    vi = _int16_volume((7, 34, 38), 21)
+    ks = [oracle.get_gaussian_kernel(1.0), oracle.get_gaussian_kernel(0.5), oracle.get_gaussian_kernel(0.5)]
+    want = numpy_seq_sweep(cv2, vi, ks, 0, 5)
+    got = oracle.OF_filter_integer_input(vi, ks, 0, 5)
+    _report("oracle int16 seq", got, want)
+    assert float(np.abs(got - want).max() / np.abs(want).max()) < TOL
+    want = numpy_par_sweep(cv2, vi, ks, 0, 5)
+    got = oracle.filter_par_integer_input(vi, ks, 0, 5).astype(np.int16)
+    _report("oracle int16 par", got, want)
+    assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
 
 
 # ---- committed cv2 fixtures (none until a box with cv2 runs tools/make_cv2_golden.py) ---------------------------
