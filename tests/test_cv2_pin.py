@@ -307,6 +307,15 @@ def test_oracle_against_committed_cv2_fixtures(oracle, path):
     if path is None:
         pytest.skip("no cv2 fixtures committed (cv2 has never been importable in this pipeline): parity unpinned")
     g = np.load(path)
+    if "semantics" in g:
+        ks = [oracle.get_gaussian_kernel(float(v)) for v in g["sigmas"]]
+        if str(g["semantics"]) == "seq":
+            got = oracle.OF_filter_integer_input(g["vol"], ks, int(g["l"]), int(g["w"]))
+            assert float(np.abs(got - g["out"]).max() / np.abs(g["out"]).max()) < TOL
+        else:
+            got = oracle.filter_par_integer_input(g["vol"], ks, int(g["l"]), int(g["w"])).astype(g["out"].dtype)
+            assert np.abs(got.astype(np.int64) - g["out"].astype(np.int64)).max() <= 1
+        return
     if "flow" in g:
         l, w = int(g["l"]), int(g["w"])
         got = oracle.get_flow(g["reference"], g["target"], l, w, g["init"].copy())

@@ -5,6 +5,7 @@ helpers); the reference's files are not involved.  Outputs are data only: seeded
 
   cv2_pair_<H>x<W>_l<l>_w<w>.npz   target, reference, init flow, cv2 flow, cv2-warped reference
   cv2_config0.npz                  128x128x64 volume (BASELINE configs[0]), sigma 2, l 0, w 5 -> seq-shaped result
+  cv2_int16_seq.npz / _par.npz     an int16 volume through seq- / par-shaped sweeps with numpy's and cv2's own dtypes
 
 After committing them, change DESIGN.md 5 to say "pinned by cv2 fixtures" (tests/test_cv2_pin.py checks it)."""
 import os
@@ -33,6 +34,13 @@ def main():
     k = O.get_gaussian_kernel(2.0)
     out = T.cv2_of_filter(cv2, vol, [k, k, k], 0, 5)
     np.savez_compressed(os.path.join(T.GOLD, "cv2_config0.npz"), vol=vol, out=out, sigma=2.0, l=0, w=5, cv2_version=cv2.__version__)
+    # integer volumes (seq: float64 padded volume; par: integer images), through sweeps that let numpy and cv2 pick the dtypes
+    vi = T._int16_volume((7, 34, 38), 21)
+    ks = [O.get_gaussian_kernel(1.0), O.get_gaussian_kernel(0.5), O.get_gaussian_kernel(0.5)]
+    np.savez_compressed(os.path.join(T.GOLD, "cv2_int16_seq.npz"), vol=vi, out=T.numpy_seq_sweep(cv2, vi, ks, 0, 5), sigmas=[1.0, 0.5, 0.5],
+                        l=0, w=5, semantics="seq", cv2_version=cv2.__version__)
+    np.savez_compressed(os.path.join(T.GOLD, "cv2_int16_par.npz"), vol=vi, out=T.numpy_par_sweep(cv2, vi, ks, 0, 5), sigmas=[1.0, 0.5, 0.5],
+                        l=0, w=5, semantics="par", cv2_version=cv2.__version__)
     print("written to", T.GOLD)
 
 
