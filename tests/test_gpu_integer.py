@@ -146,3 +146,9 @@ def test_cli_on_an_int16_mrc(fdn, oracle, tmp_path):
     r = subprocess.run(exe + ["-o", str(tmp_path / "c.mrc"), "--chunk_slices", "4"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert np.array_equal(fio.read_mrc(str(tmp_path / "c.mrc")), fio.read_mrc(str(tmp_path / "a.mrc")))
+    # sharded: every rank reads its slab in the file's dtype; the float64 mean is the exact integer sum of all slabs / count
+    for out, extra in (("d.mrc", ["--gpus", "2"]), ("e.mrc", ["--gpus", "2", "--compat", "par", "-l", "1"])):
+        r = subprocess.run(exe + ["-o", str(tmp_path / out)] + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+    assert np.array_equal(fio.read_mrc(str(tmp_path / "d.mrc")), fio.read_mrc(str(tmp_path / "a.mrc")))
+    assert np.array_equal(fio.read_mrc(str(tmp_path / "e.mrc")), fio.read_mrc(str(tmp_path / "b.mrc")))
