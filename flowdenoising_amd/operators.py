@@ -69,7 +69,7 @@ def warp_slice(reference, flow, device=0):
 
 def _filter_axis(vol, axis, kernel, l, w, mean, use_of, border_mode, chained, device):
     p = _params(l, w, use_of, border_mode, chained)
-    if border_mode == _lib.BORDER_MEAN_PAD and not isinstance(mean, np.float32):
+    if border_mode == _lib.BORDER_MEAN_PAD and np.asarray(mean).dtype not in (np.float32, np.float16):
         # seq:88: np.full(..., fill_value=mean) takes the DTYPE OF `mean`: anything but a numpy float32 (vol.mean() of an
         # integer volume, a Python float) makes the padded volume float64 -- for a float32 `vol` too
         p.warp_mode = _lib.WARP_F64_PADDED
