@@ -36,6 +36,9 @@ class SweepParams(ctypes.Structure):
 
 
 WARP_F32, WARP_F64_PADDED, WARP_ROUND_INT = 0, 1, 2
+DEPTH_F32, DEPTH_F64, DEPTH_I16, DEPTH_U16, DEPTH_I8, DEPTH_U8 = range(6)
+DEPTHS = {np.dtype(np.float32): DEPTH_F32, np.dtype(np.float64): DEPTH_F64, np.dtype(np.int16): DEPTH_I16,
+          np.dtype(np.uint16): DEPTH_U16, np.dtype(np.int8): DEPTH_I8, np.dtype(np.uint8): DEPTH_U8}
 
 
 # every symbol include/flowdn.h declares (tests check the .so exports all of them)
@@ -44,7 +47,7 @@ EXPORTS = [
     "fdn_set_workspace_limit", "fdn_workspace_bytes", "fdn_mem_info", "fdn_set_option", "fdn_malloc", "fdn_free", "fdn_memcpy_h2d", "fdn_memcpy_d2h",
     "fdn_memcpy2d_h2d", "fdn_memcpy2d_d2h", "fdn_host_register", "fdn_host_unregister",
     "fdn_memset_f32", "fdn_gaussian_kernel", "fdn_farneback", "fdn_farneback_strided", "fdn_farneback_dev",
-    "fdn_warp", "fdn_warp_strided", "fdn_warp_dev",
+    "fdn_warp", "fdn_warp_strided", "fdn_warp_dev", "fdn_farneback_typed", "fdn_warp_typed",
     "fdn_filter_axis_dev", "fdn_filter_axis", "fdn_filter_3d_dev", "fdn_filter_3d",
     "fdn_mean_host", "fdn_mean_dev", "fdn_np_chunk_sums_dev", "fdn_sum_dev", "fdn_sweep_stack_dev", "fdn_permute_dev",
     "fdn_enable_timers", "fdn_get_timers", "fdn_add_timer", "fdn_version",
@@ -235,7 +238,35 @@ class Handle:
             img = np.ascontiguousarray(img, dtype=np.float32)      # other dtypes: converted (cv2 converts to f32 too)
         return img, ctypes.c_void_p(img.ctypes.data), ctypes.c_ssize_t(img.strides[0] // 4), ctypes.c_ssize_t(img.strides[1] // 4)
 
+    @staticmethod
+    def _typed_view(img):
+        """(array, depth, pointer, row stride, column stride) of a 2-D image in one of the depths cv2 would be handed by the
+        reference (FDN_DEPTH_*); anything else is converted to float32."""
+        img = np.asarray(img)
+        depth = DEPTHS.get(img.dtype.newbyteorder("=")) if img.dtype.isnative else None
+        isz = img.dtype.itemsize
+        if depth is None or img.ndim != 2 or img.strides[0] % isz or img.strides[1] % isz:
+            img, depth, isz = np.ascontiguousarray(img, dtype=np.float32), DEPTH_F32, 4
+        return img, depth, ctypes.c_void_p(img.ctypes.data), ctypes.c_ssize_t(img.strides[0] // isz), ctypes.c_ssize_t(img.strides[1] // isz)
+
     def farneback(self, prev, next, flow, levels, winsize, iters, poly_n, poly_sigma, flags):
+        if np.asarray(prev).dtype != np.float32 or np.asarray(next).dtype != np.float32:
+            # slices of an integer MRC or of seq's float64 padded volume: converted like cv2's convertTo(CV_32F), in the library
+            prev, pd, pp, prs, pcs = self._typed_view(prev)
+            next, nd, np_, nrs, ncs = self._typed_view(next)
+            H, W = prev.shape
+            if next.shape != (H, W):
+                raise ValueError("prev and next must have the same shape")
+            if flags & USE_INITIAL_FLOW:
+                if flow is None or flow.shape != (H, W, 2) or flow.dtype != np.float32 or not flow.flags["C_CONTIGUOUS"]:
+                    raise ValueError("USE_INITIAL_FLOW needs a contiguous (H, W, 2) float32 flow")
+            else:
+                flow = np.zeros((H, W, 2), dtype=np.float32)
+            check(self._lib.fdn_farneback_typed(self._h, pp, ctypes.c_int(pd), prs, pcs, np_, ctypes.c_int(nd), nrs, ncs, _ptr(flow),
+                                                ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(int(levels)), ctypes.c_int(int(winsize)),
+                                                ctypes.c_int(int(iters)), ctypes.c_int(int(poly_n)), ctypes.c_double(float(poly_sigma)),
+                                                ctypes.c_int(int(flags))))
+            return flow
         prev, pp, prs, pcs = self._view(prev)
         next, np_, nrs, ncs = self._view(next)
         H, W = prev.shape
@@ -253,6 +284,20 @@ class Handle:
         return flow
 
     def warp(self, reference, flow):
+        """cv2.remap returns the image's own type: float64 for a slice of seq's float64 padded volume (weights in double),
+        rounded and saturated integers for a slice of an integer volume (par); float32 otherwise."""
+        ref = np.asarray(reference)
+        if not ref.dtype.isnative:              # e.g. a slice of a big-endian MRC
+            ref = ref.astype(ref.dtype.newbyteorder("="))
+        if ref.dtype != np.float32 and ref.dtype in DEPTHS:
+            ref, depth, rp, rs, cs = self._typed_view(ref)
+            flow = np.ascontiguousarray(flow, dtype=np.float32)
+            H, W = flow.shape[:2]
+            if ref.shape != (H, W) or flow.shape != (H, W, 2):
+                raise ValueError("reference (H, W) and flow (H, W, 2) shapes disagree")
+            dst = np.empty((H, W), dtype=ref.dtype)
+            check(self._lib.fdn_warp_typed(self._h, rp, ctypes.c_int(depth), rs, cs, _ptr(flow), _ptr(dst), ctypes.c_int(H), ctypes.c_int(W)))
+            return dst
         reference, rp, rs, cs = self._view(reference)
         flow = np.ascontiguousarray(flow, dtype=np.float32)
         H, W = flow.shape[:2]

@@ -226,6 +226,29 @@ static void gather_host(float* dst, const float* src, ptrdiff_t rs, ptrdiff_t cs
     }
 }
 
+// the same from an image of another depth, converted like cv::Mat::convertTo(CV_32F) (float64 -> float32 rounds to nearest)
+template <typename T, typename D = float> static void gather_host_as(D* dst, const void* src_, ptrdiff_t rs, ptrdiff_t cs, int H, int W)
+{
+    const T* src = (const T*)src_;
+    for (int r = 0; r < H; r++) {
+        const T* s = src + (ptrdiff_t)r * rs;
+        D* d = dst + (size_t)r * W;
+        for (int c = 0; c < W; c++) d[c] = (D)s[(ptrdiff_t)c * cs];
+    }
+}
+static int gather_host_depth(float* dst, const void* src, int depth, ptrdiff_t rs, ptrdiff_t cs, int H, int W)
+{
+    switch (depth) {
+    case FDN_DEPTH_F32: gather_host(dst, (const float*)src, rs, cs, H, W); return 0;
+    case FDN_DEPTH_F64: gather_host_as<double>(dst, src, rs, cs, H, W); return 0;
+    case FDN_DEPTH_I16: gather_host_as<int16_t>(dst, src, rs, cs, H, W); return 0;
+    case FDN_DEPTH_U16: gather_host_as<uint16_t>(dst, src, rs, cs, H, W); return 0;
+    case FDN_DEPTH_I8: gather_host_as<int8_t>(dst, src, rs, cs, H, W); return 0;
+    case FDN_DEPTH_U8: gather_host_as<uint8_t>(dst, src, rs, cs, H, W); return 0;
+    }
+    return fail("unknown image depth %d (FDN_DEPTH_*)", depth);
+}
+
 static size_t owned_bytes(const fdn_ctx* h)
 {
     const DevBuf* bufs[] = {&h->R, &h->M0, &h->M1, &h->flow, &h->stack, &h->sweep_out, &h->vol_a, &h->vol_b, &h->partials, &h->pair,
@@ -1214,6 +1237,102 @@ FDN_API int fdn_warp_strided(fdn_handle h, const float* reference, ptrdiff_t rs,
 FDN_API int fdn_warp(fdn_handle h, const float* reference, const float* flow, float* dst, int H, int W)
 {
     return fdn_warp_strided(h, reference, W, 1, flow, dst, H, W);
+}
+
+FDN_API int fdn_farneback_typed(fdn_handle h, const void* prev, int prev_depth, ptrdiff_t prev_rs, ptrdiff_t prev_cs,
+                                const void* next, int next_depth, ptrdiff_t next_rs, ptrdiff_t next_cs, float* flow_io, int H, int W,
+                                int levels, int winsize, int iters, int poly_n, double poly_sigma, int flags)
+{
+    FDN_ENTER(h);
+    if (!prev || !next || !flow_io) return fail("NULL image/flow pointer");
+    if (check_pair_args(H, W, levels, winsize, iters, poly_n, poly_sigma, flags)) return -1;
+    const size_t HW = (size_t)H * W;
+    hipStream_t st = h->stream;
+    PairScratch ps;
+    if (pair_scratch(h, H, W, &ps)) return -1;
+    if (ensure_pinned(h, HW * 4 * 4)) return -1;
+    float* stage = (float*)h->pinned;
+    {
+        ScopedTimer t(h, FDN_TIMER_TRANSFER);
+        // calc(): img->convertTo(fimg, CV_32F) -- whatever the two depths are
+        if (gather_host_depth(stage, prev, prev_depth, prev_rs, prev_cs, H, W)) return -1;
+        if (gather_host_depth(stage + HW, next, next_depth, next_rs, next_cs, H, W)) return -1;
+        FDN_HIP(hipMemcpyAsync(ps.img, stage, HW * 8, hipMemcpyHostToDevice, st));
+        if (flags & FDN_USE_INITIAL_FLOW) {
+            memcpy(stage + 2 * HW, flow_io, HW * 8);
+            FDN_HIP(hipMemcpyAsync(ps.flow, stage + 2 * HW, HW * 8, hipMemcpyHostToDevice, st));
+        }
+    }
+    if (farneback_pair_dev(h, ps.img, ps.R, ps.flow, ps.M0, ps.M1, H, W, levels, winsize, iters, poly_n, poly_sigma, flags)) return -1;
+    {
+        ScopedTimer t(h, FDN_TIMER_TRANSFER);
+        FDN_HIP(hipMemcpyAsync(stage + 2 * HW, ps.flow, HW * 8, hipMemcpyDeviceToHost, st));
+        FDN_HIP(hipStreamSynchronize(st));
+        memcpy(flow_io, stage + 2 * HW, HW * 8);
+    }
+    return 0;
+}
+
+FDN_API int fdn_warp_typed(fdn_handle h, const void* reference, int depth, ptrdiff_t rs, ptrdiff_t cs, const float* flow, void* dst, int H, int W)
+{
+    if (depth == FDN_DEPTH_F32) return fdn_warp_strided(h, (const float*)reference, rs, cs, flow, (float*)dst, H, W);
+    FDN_ENTER(h);
+    if (check_warp_args(reference, flow, dst, H, W)) return -1;
+    if (depth == FDN_DEPTH_I8) return fail("cv2.remap does not support 8-bit signed images (the reference raises there)");
+    if (depth == FDN_DEPTH_U8) return fail("cv2.remap interpolates 8-bit unsigned images in fixed point; that path is not restated");
+    if (depth != FDN_DEPTH_F64 && depth != FDN_DEPTH_I16 && depth != FDN_DEPTH_U16) return fail("unknown image depth %d (FDN_DEPTH_*)", depth);
+    const size_t HW = (size_t)H * W;
+    hipStream_t st = h->stream;
+    if (depth == FDN_DEPTH_F64) {      // remapBilinear<Cast<double, double>, ., float>: doubles in, doubles out
+        if (ensure(h, h->pair, HW * 8 * 3)) return -1;
+        if (ensure_pinned(h, HW * 8 * 3)) return -1;
+        double* d_src = (double*)h->pair.p;
+        double* d_dst = d_src + HW;
+        float* d_flow = (float*)(d_dst + HW);
+        double* stage = (double*)h->pinned;
+        {
+            ScopedTimer t(h, FDN_TIMER_TRANSFER);
+            gather_host_as<double, double>(stage, reference, rs, cs, H, W);
+            memcpy(stage + 2 * HW, flow, HW * 8);
+            FDN_HIP(hipMemcpyAsync(d_src, stage, HW * 8, hipMemcpyHostToDevice, st));
+            FDN_HIP(hipMemcpyAsync(d_flow, stage + 2 * HW, HW * 8, hipMemcpyHostToDevice, st));
+        }
+        launch_warp_f64(d_src, d_flow, d_dst, H, W, st);
+        FDN_HIP(hipGetLastError());
+        ScopedTimer t(h, FDN_TIMER_TRANSFER);
+        FDN_HIP(hipMemcpyAsync(stage + HW, d_dst, HW * 8, hipMemcpyDeviceToHost, st));
+        FDN_HIP(hipStreamSynchronize(st));
+        memcpy(dst, stage + HW, HW * 8);
+        return 0;
+    }
+    // 16-bit integers: remapBilinear<Cast<float, T>>: float arithmetic on the (exactly converted) values, then
+    // saturate_cast<T>(float) = cvRound (half to even), clamped to the type's range
+    if (ensure(h, h->pair, HW * 4 * 4)) return -1;
+    if (ensure_pinned(h, HW * 4 * 4)) return -1;
+    float* d_src = (float*)h->pair.p;
+    float* d_flow = d_src + HW;
+    float* d_dst = d_flow + 2 * HW;
+    float* stage = (float*)h->pinned;
+    {
+        ScopedTimer t(h, FDN_TIMER_TRANSFER);
+        if (gather_host_depth(stage, reference, depth, rs, cs, H, W)) return -1;
+        memcpy(stage + HW, flow, HW * 8);
+        FDN_HIP(hipMemcpyAsync(d_src, stage, HW * 12, hipMemcpyHostToDevice, st));
+    }
+    launch_warp(d_src, d_flow, d_dst, H, W, st);
+    FDN_HIP(hipGetLastError());
+    ScopedTimer t(h, FDN_TIMER_TRANSFER);
+    FDN_HIP(hipMemcpyAsync(stage + 3 * HW, d_dst, HW * 4, hipMemcpyDeviceToHost, st));
+    FDN_HIP(hipStreamSynchronize(st));
+    const float* res = stage + 3 * HW;
+    if (depth == FDN_DEPTH_I16) {
+        int16_t* o = (int16_t*)dst;
+        for (size_t i = 0; i < HW; i++) o[i] = (int16_t)fminf(fmaxf(rintf(res[i]), -32768.f), 32767.f);
+    } else {
+        uint16_t* o = (uint16_t*)dst;
+        for (size_t i = 0; i < HW; i++) o[i] = (uint16_t)fminf(fmaxf(rintf(res[i]), 0.f), 65535.f);
+    }
+    return 0;
 }
 
 FDN_API int fdn_warp_dev(fdn_handle h, const float* d_reference, ptrdiff_t rs, ptrdiff_t cs, const float* d_flow, float* d_dst, int H, int W)

@@ -280,6 +280,25 @@ static __device__ __forceinline__ double remap_finish_f64(const RemapTaps& r, bo
     return v0 * (double)w0 + v1 * (double)w1 + v2 * (double)w2 + v3 * (double)w3;
 }
 
+// the same remap for a CV_64F image held as doubles (fdn_warp_typed): coordinates and weights as remap_issue / remap_finish_f64
+static __device__ __forceinline__ double remap_sample_f64(const double* __restrict__ src, int H, int W, int x, int y, float2 f)
+{
+    float mx = (float)((double)f.x + (double)x);
+    float my = (float)((double)f.y + (double)y);
+    float qx = fminf(fmaxf(rintf(mx * 32.f), -2147483520.f), 2147483520.f);
+    float qy = fminf(fmaxf(rintf(my * 32.f), -2147483520.f), 2147483520.f);
+    int sx = (int)qx, sy = (int)qy;
+    const int ax = sx & 31, ay = sy & 31;
+    int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);
+    int xa = clampi(ix, 0, W - 1), xb = clampi(ix + 1, 0, W - 1);
+    int ya = clampi(iy, 0, H - 1), yb = clampi(iy + 1, 0, H - 1);
+    const size_t oa = (size_t)ya * W, ob = (size_t)yb * W;
+    float tx1 = (float)ax * (1.f / 32), tx0 = 1.f - tx1;
+    float ty1 = (float)ay * (1.f / 32), ty0 = 1.f - ty1;
+    float w0 = ty0 * tx0, w1 = ty0 * tx1, w2 = ty1 * tx0, w3 = ty1 * tx1;
+    return src[oa + xa] * (double)w0 + src[oa + xb] * (double)w1 + src[ob + xa] * (double)w2 + src[ob + xb] * (double)w3;
+}
+
 static __device__ __forceinline__ float remap_sample(const float* __restrict__ src, int H, int W, int x, int y, float2 f)
 {
     RemapTaps r;

@@ -71,6 +71,8 @@ void launch_axpy_slices(const float* stack, float* acc, PairBatch pb, int H, int
 void launch_trunc_clamp(float* v, size_t count, float lo, float hi, hipStream_t st);
 // dst(y,x) = remap(src, flow)  single image (fdn_warp)
 void launch_warp(const float* src, const float* flow, float* dst, int H, int W, hipStream_t st);
+// the same for a CV_64F image: double in, double out (cv2.remap's Cast<double, double> path)
+void launch_warp_f64(const double* src, const float* flow, double* dst, int H, int W, hipStream_t st);
 
 // Per-handle switches: read from the environment once, at fdn_create, and changed with fdn_set_option
 // (tests and experiments; every path gives the same bits except strict_order).

@@ -547,6 +547,21 @@ void launch_warp(const float* src, const float* flow, float* dst, int H, int W, 
     hipLaunchKernelGGL(k_warp, grid, dim3(256), 0, st, src, flow, dst, H, W);
 }
 
+__global__ __launch_bounds__(256) void k_warp_f64(const double* __restrict__ src, const float* __restrict__ flow_base,
+                                                  double* __restrict__ dst, int H, int W)
+{
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    size_t o = (size_t)y * W + x;
+    dst[o] = remap_sample_f64(src, H, W, x, y, ((const float2*)flow_base)[o]);
+}
+void launch_warp_f64(const double* src, const float* flow, double* dst, int H, int W, hipStream_t st)
+{
+    dim3 grid((W + 63) / 64, (H + 3) / 4, 1);
+    hipLaunchKernelGGL(k_warp_f64, grid, dim3(256), 0, st, src, flow, dst, H, W);
+}
+
 __global__ __launch_bounds__(256) void k_axpy_slices(const float* __restrict__ stack, float* __restrict__ acc_base,
                                                      PairBatch pb, size_t HW, double weight, WarpMode wm)
 {

@@ -160,6 +160,25 @@ int fdn_warp_strided(fdn_handle h, const float* reference, ptrdiff_t row_stride,
 int fdn_warp_dev(fdn_handle h, const float* d_reference, ptrdiff_t row_stride, ptrdiff_t col_stride,
                  const float* d_flow, float* d_dst, int H, int W);
 
+/* ---- the pair operators on images that are not float32 ------------------------------------------------------
+ * The reference hands cv2 whatever its arrays are: slices of an integer MRC (par:312, dtype of the file) or of the
+ * float64 padded volume seq:88-89 builds from one.  cv2.calcOpticalFlowFarneback converts both images to float32
+ * (convertTo(CV_32F)); cv2.remap computes per depth and returns the image's type: CV_64F weights in double without
+ * rounding to float, CV_16S / CV_16U in float and then rounds half to even and saturates; CV_8S is not supported by
+ * cv2.remap (error here too) and CV_8U (fixed-point interpolation) is not restated (error).  HOST pointers; strides
+ * in elements of the image's type; flow (H x W x 2 float32) and dst (H x W, the reference's type) contiguous. */
+#define FDN_DEPTH_F32 0
+#define FDN_DEPTH_F64 1
+#define FDN_DEPTH_I16 2
+#define FDN_DEPTH_U16 3
+#define FDN_DEPTH_I8 4
+#define FDN_DEPTH_U8 5
+int fdn_farneback_typed(fdn_handle h, const void* prev, int prev_depth, ptrdiff_t prev_row_stride, ptrdiff_t prev_col_stride,
+                        const void* next, int next_depth, ptrdiff_t next_row_stride, ptrdiff_t next_col_stride,
+                        float* flow_inout, int H, int W, int levels, int winsize, int iters, int poly_n, double poly_sigma, int flags);
+int fdn_warp_typed(fdn_handle h, const void* reference, int depth, ptrdiff_t row_stride, ptrdiff_t col_stride,
+                   const float* flow, void* dst, int H, int W);
+
 /* ---- a-5/6/7/10  OF_filter_along_{Z,Y,X} (seq:78-130, 235-288, 313-364),
  *      no_OF_filter_along_* (seq:171-192, 290-311, 396-417),
  *      FlowDenoising.filter_along_*_slice (par:306-373) ----------------------------- */

@@ -152,3 +152,39 @@ def test_cli_on_an_int16_mrc(fdn, oracle, tmp_path):
         assert r.returncode == 0, r.stderr[-3000:]
     assert np.array_equal(fio.read_mrc(str(tmp_path / "d.mrc")), fio.read_mrc(str(tmp_path / "a.mrc")))
     assert np.array_equal(fio.read_mrc(str(tmp_path / "e.mrc")), fio.read_mrc(str(tmp_path / "b.mrc")))
+
+
+def _map_of(flow):
+    H, W = flow.shape[:2]
+    m = np.empty((H, W, 2), np.float32)
+    m[..., 0] = (flow[..., 0].astype(np.float64) + np.arange(W)[None, :]).astype(np.float32)     # seq:53-55
+    m[..., 1] = (flow[..., 1].astype(np.float64) + np.arange(H)[:, None]).astype(np.float32)
+    return m
+
+
+def test_pair_operators_on_the_reference_s_own_dtypes(fdn, oracle):
+    """get_flow / warp_slice on what the reference hands cv2 for an integer MRC: slices of the volume itself (par) or
+    of the float64 padded volume (seq), as strided views.  Farneback converts to float32; remap returns the
+    image's type (fdn_farneback_typed / fdn_warp_typed)."""
+    from flowdenoising_amd import _lib
+    vol = _int_vol((9, 40, 44), 18, np.int16, 1200)
+    rng = np.random.default_rng(5)
+    padded = np.full(shape=(9 + 5, 40, 44), fill_value=vol.mean())                 # seq:88: float64
+    padded[2:11] = vol
+    for ref, tgt in ((vol[:, 7, :], vol[:, 8, :]),                                  # par: int16 views (row-strided)
+                     (vol.astype(np.uint16)[:, :, 5], vol.astype(np.uint16)[:, :, 6]),   # element-strided uint16
+                     (padded[:, :, 9], vol[:, :, 9]),                               # seq: float64 reference, int16 target
+                     (padded[1], padded[2])):                                       # a pad slice (constant float64 mean)
+        H, W = ref.shape
+        if tgt.shape != ref.shape:
+            tgt = np.ascontiguousarray(tgt)
+            ref = ref[:tgt.shape[0]]
+            H, W = ref.shape
+        f0 = (rng.standard_normal((H, W, 2)) * 0.7).astype(np.float32)
+        want_flow = oracle.get_flow(np.asarray(ref, np.float32), np.asarray(tgt, np.float32), 0, 5, f0.copy())
+        got_flow = fdn.get_flow(ref, tgt, 0, 5, f0.copy())
+        assert np.array_equal(got_flow, want_flow)
+        warped = fdn.warp_slice(ref, got_flow)
+        assert warped.dtype == ref.dtype and np.array_equal(warped, oracle.remap_any(np.ascontiguousarray(ref), _map_of(got_flow)))
+    with pytest.raises(_lib.FlowdnError):                                            # CV_8S: cv2.remap has no such path
+        fdn.warp_slice((vol[0] // 40).astype(np.int8), np.zeros((40, 44, 2), np.float32))
