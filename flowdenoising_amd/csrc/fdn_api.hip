@@ -594,6 +594,8 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
     const int r = K / 2;
     const size_t HW = (size_t)H * W;
     hipStream_t st = h->stream;
+    if (p->warp_mode == FDN_WARP_F64_PADDED && (long)p->pad_lo + p->pad_hi > (long)S + 2 * r)
+        return fail("pad_lo + pad_hi = %d + %d exceeds the stack's %d slices", p->pad_lo, p->pad_hi, S + 2 * r);
     const WarpMode wm_all = warp_mode_of(p, S, r);   // pad slices in the coordinates of the whole stack
     const bool plain = wm_all.kind == FDN_WARP_F32;  // otherwise: flows from the Farneback kernels, folding by k_sweep_side
 
