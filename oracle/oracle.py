@@ -212,6 +212,22 @@ def filter_axis_range(vol, axis, kernel, l, w, mean, s0, s1, use_of=True, border
     return out
 
 
+def filter_axis_range_integer(vol, axis, kernel, l, w, mean64, s0, s1, semantics="seq", nthreads=1, chained=True, int_range=None):
+    """filter_axis_range under the integer-volume semantics: "seq" = float64 padded volume with the float64 mean `mean64`
+    (only slices outside `vol` count as pad slices), "par" = integer images in `int_range` = (lo, hi), wrap-around."""
+    if semantics == "seq":
+        lib().fdo_set_f64_padded(ctypes.c_int(1), ctypes.c_double(float(mean64)))
+        try:
+            return filter_axis_range(vol, axis, kernel, l, w, np.float32(mean64), s0, s1, nthreads=nthreads, chained=chained)
+        finally:
+            lib().fdo_set_f64_padded(ctypes.c_int(0), ctypes.c_double(0.0))
+    lib().fdo_set_int_round(ctypes.c_int(1), ctypes.c_double(int_range[0]), ctypes.c_double(int_range[1]))
+    try:
+        return filter_axis_range(vol, axis, kernel, l, w, 0.0, s0, s1, border_mode=1, nthreads=nthreads, chained=chained)
+    finally:
+        lib().fdo_set_int_round(ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0))
+
+
 def OF_filter_along_Z(vol, kernel, l, w, mean, **kw):
     return filter_along_axis(vol, 0, kernel, l, w, mean, **kw)
 

@@ -188,3 +188,24 @@ def test_pair_operators_on_the_reference_s_own_dtypes(fdn, oracle):
         assert warped.dtype == ref.dtype and np.array_equal(warped, oracle.remap_any(np.ascontiguousarray(ref), _map_of(got_flow)))
     with pytest.raises(_lib.FlowdnError):                                            # CV_8S: cv2.remap has no such path
         fdn.warp_slice((vol[0] // 40).astype(np.int8), np.zeros((40, 44, 2), np.float32))
+
+
+@pytest.mark.parametrize("l,w", [(0, 5), (3, 15)])
+def test_integer_semantics_on_full_size_images(fdn, oracle, l, w):
+    """1024 x 1024 images of an int16 volume (configs[2]'s slices), Z pass: one interior target slice under seq's
+    semantics (all 16 neighbours real: the double-precision remap) and one under par's (wrap-around, rounded remap,
+    truncated result) against the oracle on the sub-volume that feeds them."""
+    from flowdenoising_amd import _lib
+    from flowdenoising_amd.operators import _params, handle, integer_semantics
+    vol = _int_vol((20, 1024, 1024), 19, np.int16, 2000)
+    k = fdn.get_gaussian_kernel(2.0)
+    r = k.size // 2
+    t = 10
+    got = fdn.OF_filter(vol, [k, None, None], l, w)
+    sub = vol[t - r:t + r + 1]
+    want = oracle.filter_axis_range_integer(sub, 0, k, l, w, float(vol.mean()), r, r + 1)
+    assert np.array_equal(got[t], want[r])
+    p = integer_semantics(vol, _params(l, w, True, _lib.BORDER_WRAP))
+    got = handle().filter_axis(vol, 0, k, 0.0, p)
+    want = oracle.filter_axis_range_integer(sub, 0, k, l, w, 0.0, r, r + 1, semantics="par", int_range=(-32768, 32767))
+    assert np.array_equal(got[t], want[r])
