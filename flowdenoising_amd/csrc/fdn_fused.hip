@@ -76,7 +76,9 @@ static __device__ __forceinline__ void lds_barrier()
 // 17.58 ms per launch, same box) -- the two bands are neighbours in the image and stay in step, so the columns they share
 // and the R1 rows both stream arrive once per CU.
 template <int MH, int D, int DX, int U, int OCC, int FIN, bool ACC, int NB>
-__global__ __launch_bounds__(256 * NB, NB == 2 ? 2 : OCC) void k_farneback_fused(const float* __restrict__ Rstack, const float* __restrict__ stack,
+// (the second argument of __launch_bounds__ is waves per SIMD: for a 4-wave workgroup that is workgroups per CU; the
+// 8-wave workgroup runs two per CU, i.e. the same 4)
+__global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused(const float* __restrict__ Rstack, const float* __restrict__ stack,
                                                          const float* __restrict__ flow_in_base, float* __restrict__ flow_out_base,
                                                          float* __restrict__ acc_base, PairBatch pb, int H, int W,
                                                          double scale, double weight, int nbands, FlowSource fs)
