@@ -40,6 +40,9 @@
 #include "fdn_device.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <algorithm>
+#include <utility>
+#include <vector>
 
 namespace fdn {
 
@@ -411,9 +414,17 @@ static void launch_variant(const float* Rstack, const float* stack, const float*
     const int nbands = (W + BW - 1) / BW;
     dim3 grid((unsigned)(((long)nbands * pb.npairs + NB - 1) / NB));
     auto launch = [&](auto kern) {
-        const unsigned lds = NB * win_bytes + lds_pad;
-        // above 64 KB of dynamic LDS a kernel must be told so (cheap; per launch, so every device the library runs on is covered)
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const unsigned lds = NB * win_bytes + (NB == 1 ? lds_pad : 0);     // lds_pad: an occupancy experiment knob of the one-band build
+        if (lds > 64 * 1024) {      // above 64 KB of dynamic LDS a kernel must be told so: once per kernel, device and host thread
+            static thread_local std::vector<std::pair<const void*, int>> told;
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            const std::pair<const void*, int> key((const void*)kern, dev);
+            if (std::find(told.begin(), told.end(), key) == told.end()) {
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                told.push_back(key);
+            }
+        }
         hipLaunchKernelGGL(kern, grid, dim3(256 * NB), lds, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, fs);
     };
     const int fin = !flow_in ? 0 : fs.h > 0 ? 2 : 1;
