@@ -19,9 +19,9 @@ print("ok", sys.argv[1:], flush=True)
 '''
 outs = []
 for l in (0, 3):
-    for occ in ("3", "4", "5"):
-        fn = f"/tmp/soak_{l}_{occ}.npy"
-        env = dict(os.environ, FDN_FUSED_OCC=occ)
+    for occ in ("", "3", "4", "5"):           # "": the launcher's own choice (two bands per workgroup on large grids)
+        fn = f"/tmp/soak_{l}_{occ or 'auto'}.npy"
+        env = dict(os.environ, FDN_FUSED_OCC=occ) if occ else {k: v for k, v in os.environ.items() if k != "FDN_FUSED_OCC"}
         subprocess.run([sys.executable, "-c", code, str(l), fn, "5"], env=env, check=True)
         outs.append((l, fn))
 # the one-iteration kernel (winsize 15): its own runs, and against the per-stage kernels
