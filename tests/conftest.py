@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the HIP runtime reports its own errors on stderr (level 1 = errors only): a failure inside the runtime then says what it was
+os.environ.setdefault("AMD_LOG_LEVEL", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
