@@ -82,7 +82,7 @@ def _run(world, shape, sigmas, border_mode=0, use_of=True):
     return res
 
 
-@pytest.mark.parametrize("world,shape", [(2, (12, 34, 36)), (3, (11, 34, 37)), (4, (10, 33, 35))])
+@pytest.mark.parametrize("world,shape", [(2, (12, 34, 36)), (3, (11, 34, 37)), (4, (10, 33, 35)), (8, (16, 40, 42))])
 def test_sharded_of_filter_equals_single_process(oracle, world, shape):
     from flowdenoising_amd.synth import make_volume
     sig = (1.0, 0.5, 1.0)
@@ -127,7 +127,8 @@ def test_exchange_schedule_is_consistent():
     """Sender and receiver derive the same block list; the blocks a rank receives tile its halo-extended stack
     exactly once (positions outside a mean-padded volume excepted)."""
     from flowdenoising_amd.distributed import ORIENT, SlabPlan
-    for world, shape, r, wrap in [(3, (7, 9, 11), 2, False), (2, (5, 6, 7), 3, True), (4, (9, 8, 10), 1, True), (3, (6, 7, 8), 0, False)]:
+    for world, shape, r, wrap in [(3, (7, 9, 11), 2, False), (2, (5, 6, 7), 3, True), (4, (9, 8, 10), 1, True), (3, (6, 7, 8), 0, False),
+                                  (8, (16, 24, 17), 4, False), (8, (9, 8, 16), 8, True)]:      # the scaling run's rank count; halos spanning several slabs
         for A in range(3):
             for B in range(3):
                 for j in range(world):
