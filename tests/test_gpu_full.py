@@ -120,7 +120,8 @@ def test_slab_engine_on_hip_backend_world1(fdn, oracle):
     assert rel_err(out, want) < TIGHT_TOL
 
 
-@pytest.mark.parametrize("world,shape,sig,border,l", [(2, (12, 70, 150), "1.0,0.5,1.0", 0, 0), (3, (13, 64, 128), "1.0,-,0.5", 1, 1)])
+@pytest.mark.parametrize("world,shape,sig,border,l", [(2, (12, 70, 150), "1.0,0.5,1.0", 0, 0), (3, (13, 64, 128), "1.0,-,0.5", 1, 1),
+                                                      (4, (10, 66, 140), "1.5,0.5,1.0", 0, 0)])    # 4 ranks + this process: under the box's limit of 6
 def test_slab_engine_on_hip_backend_multi_rank(fdn, tmp_path, world, shape, sig, border, l):
     """N > 1 on the HIP backend: `world` processes, each with its own fdn handle, run the slab engine (persistent
     buffers, fdn_permute_dev packing, one exchange per pass, the chunk-sum mean) and must reproduce the single-GPU
