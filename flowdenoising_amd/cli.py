@@ -3,7 +3,7 @@
 Same options as the reference (union of src/flowdenoising_sequential.py:446-473 and
 src/flowdenoising.py:384-415): -i/--input, -o/--output, -s/--sigma (Z Y X), -l/--levels,
 -w/--winsize, -v/--verbosity, -n/--no_OF, -m/--memory_map, -p/--number_of_processes,
---recompute_flow, --show_fingerprint.  File-type dispatch and output dtypes follow seq:508-571.
+--recompute_flow, --show_fingerprint (and, ignored, flowdenoising_GPU.py's --use_GPU / --use_threads).  File-type dispatch and output dtypes follow seq:508-571.
 
 Defaults follow the parity oracle, flowdenoising_sequential.py: levels = 0, volume ends padded
 with the global mean, full Z->Y->X result.  `--compat par` switches to flowdenoising.py's own
@@ -60,6 +60,9 @@ def build_parser():
                    help="Accepted for compatibility; slices are batched on the GPU instead of a process pool")
     p.add_argument("--recompute_flow", action="store_true", help="Disable the use of adjacent optical flow fields")
     p.add_argument("--show_fingerprint", action="store_true", help="Show a hash of this program")
+    # src/flowdenoising_GPU.py:597-598: accepted so that its command lines keep working; the flow always runs on the GPU here
+    p.add_argument("--use_GPU", action="store_true", help="Accepted for compatibility (the optical flow always runs on the GPU)")
+    p.add_argument("--use_threads", action="store_true", help="Accepted for compatibility (no process pool here)")
     p.add_argument("--compat", choices=("seq", "par"), default="seq",
                    help="seq: flowdenoising_sequential.py semantics (mean-padded ends, levels 0); "
                         "par: flowdenoising.py semantics (wrap-around ends, levels 3, float32 TIFF)")

@@ -159,6 +159,8 @@ def test_cli_options_match_the_reference():
     a = p.parse_args("-i in.tif -o out.MRC -s 1 2 3 -l 2 -w 7 -v 2 -n -m -p 4 --recompute_flow".split())
     assert (a.input, a.output, a.sigma, a.levels, a.winsize, a.verbosity) == ("in.tif", "out.MRC", ["1", "2", "3"], 2, 7, 2)
     assert a.no_OF and a.memory_map and a.recompute_flow and a.number_of_processes == 4
+    a = p.parse_args("--use_GPU --use_threads --show_fingerprint".split())             # gpu:597-598 command lines keep parsing
+    assert a.use_GPU and a.use_threads and a.show_fingerprint
 
 
 def test_slab_plan():
