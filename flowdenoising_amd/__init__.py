@@ -10,4 +10,6 @@ from .operators import (  # noqa: F401
     no_OF_filter_along_X, no_OF_filter_along_Y, no_OF_filter_along_Z, warp_slice,
 )
 
+from .flower import CPU_flower, GPU_flower  # noqa: F401,E402
+
 __version__ = "0.1.0"

@@ -333,3 +333,23 @@ def test_device_mean_is_numpys_float32_mean(fdn, n):
         assert np.array_equal(h.np_chunk_sums_dev(d, n), [a[s:s + 8192].sum(dtype=np.float32) for s in range(0, n, 8192)])
     finally:
         h.free(d)
+
+
+def test_flower_protocol(fdn, oracle):
+    """src/flowdenoising_GPU.py's flower objects (gpu:92-177): set_target once, then a chain of get_flow(reference, prev_flow)
+    calls -- the target stays on the device; flows equal cv2-order Farneback (the oracle) call by call, with and without
+    OPTFLOW_USE_INITIAL_FLOW."""
+    vol = _vol((6, 70, 90), seed=51)
+    fl = fdn.GPU_flower(1, 5, 3, 5, 1.2)
+    fl.set_target(vol[2])
+    flow = np.zeros((70, 90, 2), np.float32)
+    want = flow.copy()
+    for i in (3, 4, 5):
+        flow = fl.get_flow(vol[i], flow)
+        want = oracle.get_flow(vol[i], vol[2], 1, 5, want)
+        assert np.array_equal(flow, want)
+    cold = fdn.CPU_flower(l=0, w=7, flags=0)
+    cold.set_target(vol[0])
+    assert np.array_equal(cold.get_flow(vol[1]), oracle.calcOpticalFlowFarneback(vol[0], vol[1], None, 0.5, 0, 7, 3, 5, 1.2, 0))
+    with pytest.raises(RuntimeError):
+        fdn.CPU_flower().get_flow(vol[0], flow)
