@@ -288,6 +288,30 @@ def test_integer_volumes_against_cv2(oracle):
     assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
 
 
+@pytest.mark.gpu
+def test_hip_integer_volumes_against_cv2(fdn):
+    """The HIP path on an int16 volume against the same reference-shaped sweeps on real cv2 (seq and par semantics),
+    and the typed pair operators against cv2 called on the same arrays."""
+    cv2 = pytest.importorskip("cv2")
+    vi = _int16_volume((7, 34, 38), 21)
+    ks = [fdn.get_gaussian_kernel(1.0), fdn.get_gaussian_kernel(0.5), fdn.get_gaussian_kernel(0.5)]
+    want = numpy_seq_sweep(cv2, vi, ks, 0, 5)
+    got = fdn.OF_filter(vi, ks, 0, 5)
+    _report("hip int16 seq", got, want)
+    assert float(np.abs(got - want).max() / np.abs(want).max()) < TOL
+    want = numpy_par_sweep(cv2, vi, ks, 0, 5)
+    v = vi.copy()
+    fdn.FlowDenoising(1, v, 0, 5).filter(ks)
+    _report("hip int16 par", v, want)
+    assert np.abs(v.astype(np.int32) - want.astype(np.int32)).max() <= 1
+    padded = np.full(shape=(9, 34, 38), fill_value=vi.mean())
+    padded[1:8] = vi
+    flow = cv2_flow(cv2, vi[3], padded[5], 0, 5, np.zeros((34, 38, 2), np.float32))
+    assert _flow_err(fdn.get_flow(padded[5], vi[3], 0, 5, np.zeros((34, 38, 2), np.float32)), flow) < TOL
+    for ref in (padded[5], vi[4], vi[4].astype(np.uint16)):
+        assert np.array_equal(fdn.warp_slice(ref, flow), cv2_warp(cv2, ref, flow))
+
+
 # ---- committed cv2 fixtures (none until a box with cv2 runs tools/make_cv2_golden.py) ---------------------------
 def _fixtures():
     return sorted(glob.glob(os.path.join(GOLD, "cv2_*.npz")))
