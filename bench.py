@@ -32,7 +32,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 KERNEL_SOURCES = ("fdn_fused.hip", "fdn_iter.hip", "fdn_device.h", "fdn_kernels.hip")
 
 
@@ -120,25 +119,36 @@ def roofline(timers, nvox, K, levels, run_cfg):
 
 
 def committed_profile(kernel, run_cfg):
-    """PMC traffic of the dominant kernel from profiles/ (tools/profile_round.sh).  Used only when it was taken
-    from the same kernel sources and the same workload as this run; otherwise traffic stays null."""
-    if not os.path.exists(TRAFFIC_FILE):
+    """PMC traffic of the dominant kernel from profiles/*_traffic.json (tools/profile_round.sh, tools/profile_w15.sh).
+    The file whose kernel, kernel sources (sha) and workload all match this run is used, newest round first;
+    otherwise traffic stays null and the reason is reported."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True)
+    if not files:
         return {"note": "no committed PMC pass"}
-    with open(TRAFFIC_FILE) as f:
-        t = json.load(f)
-    if t.get("kernel") != kernel:
-        return {"note": f"committed PMC pass is for {t.get('kernel')}, not {kernel}"}
-    if t.get("kernel_source_sha") != kernel_source_hash():
-        print(f"bench.py: WARNING: {os.path.basename(TRAFFIC_FILE)} was profiled on other kernel sources "
-              f"({t.get('kernel_source_sha')} != {kernel_source_hash()}): roofline.traffic left null; rerun tools/profile_round.sh",
-              file=sys.stderr)
-        return {"note": "committed PMC pass is STALE (kernel sources changed since): not used"}
-    for key in ("shape", "winsize", "levels", "sigma", "axes"):
-        if t.get("workload", {}).get(key) != run_cfg.get(key):
-            return {"note": f"committed PMC pass is for another workload ({key}): not used"}
-    return {"bytes_per_px": t["bytes_per_pixel"], "limiter": t.get("limiter"),
-            "note": f"source: committed profile {os.path.basename(TRAFFIC_FILE)} (commit {t.get('commit')}, `{t.get('command')}`): "
-                    "(2 x FETCH_SIZE + WRITE_SIZE) per launch from separate rocprofv3 --pmc passes, not measured in this run"}
+    sha = kernel_source_hash()
+    why = []
+    for fn in files:
+        with open(fn) as f:
+            t = json.load(f)
+        base = os.path.basename(fn)
+        if not str(t.get("kernel", "")).startswith(kernel):
+            why.append(f"{base}: kernel {t.get('kernel')}")
+            continue
+        bad = [key for key in ("shape", "winsize", "levels", "sigma", "axes") if t.get("workload", {}).get(key) != run_cfg.get(key)]
+        if bad:
+            why.append(f"{base}: another workload ({', '.join(bad)})")
+            continue
+        if t.get("kernel_source_sha") != sha:
+            why.append(f"{base}: STALE (kernel sources {t.get('kernel_source_sha')} != {sha})")
+            continue
+        return {"bytes_per_px": t["bytes_per_pixel"], "limiter": t.get("limiter"),
+                "note": f"source: committed profile {base} (commit {t.get('commit')}, `{t.get('command')}`): "
+                        "(2 x FETCH_SIZE + WRITE_SIZE) per launch from separate rocprofv3 --pmc passes, not measured in this run"}
+    if any("STALE" in w for w in why):
+        print("bench.py: WARNING: the committed PMC pass of this kernel and workload was taken on other kernel sources: "
+              "roofline.traffic left null; rerun tools/profile_round.sh", file=sys.stderr)
+    return {"note": "no committed PMC pass matches this run -- " + "; ".join(why)}
 
 
 def sweep_line(h, vol, shape, kernel, params, mean):
@@ -243,8 +253,27 @@ def cpu_baseline(vol_t, shape, kernel, mean, n_targets, levels, winsize):
                       "reference itself would be slower than this"}
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` from a bare shell (how the driver calls it): start the N ranks as a CHILD process
+    under torch.distributed.run -- before anything here imports torch or touches the GPU, and never by exec --,
+    relay rank 0's JSON line and return the child's exit code."""
+    port = int(os.environ.get("MASTER_PORT", 0)) or 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "2")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    for line in proc.stdout:                                 # stderr goes straight through; stdout carries the JSON line
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(a))
     import torch
     import torch.distributed as dist
     from flowdenoising_amd import _lib, synth
@@ -252,9 +281,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != a.gpus:          # launched by torch.distributed.run with another rank count: the environment decides
         a.gpus = world
     rehearsal = world > 1 and torch.cuda.device_count() < world
     if rehearsal:            # fewer GPUs than ranks (a one-GPU box): the ranks share GPU 0 and exchange through the host
@@ -354,6 +381,8 @@ def main():
             "value": round(value, 3), "unit": "Mvoxels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
+            "backend": (dist.get_backend() if world > 1 else "none"),
             "config": {"workload": f"{X}x{Y}x{Z} float32, sigma={a.sigma:g} (K={kernel.size}), levels={a.levels}, winsize={a.winsize}, "
                                    f"OF along {a.axes.upper()}, mean-padded borders (BASELINE.json configs[2])",
                        "axes": a.axes, "parallelism": parallelism, "amplitude": a.amplitude,

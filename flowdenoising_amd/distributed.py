@@ -160,10 +160,14 @@ class SlabEngine:
     ORIENT = ORIENT
     PHASES = ("compute", "pack", "exchange", "unpack", "mean")
 
-    def __init__(self, plan, backend, dist=None):
+    def __init__(self, plan, backend, dist=None, loopback=False):
+        """loopback: route the blocks a rank keeps for itself through the transport too (a send to self inside the
+        batched group) and take the mean through the all_gather even with one rank -- so that a world-size-1 run on
+        one GPU carries real RCCL calls in exactly the shapes an N > 1 run issues (a test switch; slower)."""
         import torch
         self.torch = torch
         self.plan, self.backend, self.dist = plan, backend, dist
+        self.loopback = bool(loopback) and dist is not None
         if hasattr(backend, "sweep_stack_dev"):  # a bare fdn handle was passed
             self.backend = HipBackend(backend)
         self._bufs = {}
@@ -233,6 +237,15 @@ class SlabEngine:
     def _p2p(self, recvs, sends):
         """recvs: [(tensor, src rank)], sends: [(tensor, dst rank)] -- one batched group, every pair at once."""
         dist = self.dist
+        if dist.get_backend() != "nccl":     # RCCL carries a send to self inside a group; gloo has no pair to oneself:
+            me = self.plan.rank              # match those messages here, in order (loopback mode only)
+            own_r = [t for t, r in recvs if r == me]
+            own_s = [t for t, r in sends if r == me]
+            assert len(own_r) == len(own_s)
+            for d, s_ in zip(own_r, own_s):
+                d.copy_(s_)
+            recvs = [(t, r) for t, r in recvs if r != me]
+            sends = [(t, r) for t, r in sends if r != me]
         if not recvs and not sends:
             return
         if (recvs and self._host_staged(recvs[0][0])) or (sends and self._host_staged(sends[0][0])):
@@ -281,7 +294,8 @@ class SlabEngine:
         oa, ob = ORIENT[A], ORIENT[B]
         sends, recvs = self._schedule(A, B, r, wrap)
         n_send = sum(self._numel(rng) for _, bl in sends for _, rng in bl)
-        n_recv = sum(self._numel(rng) for i, bl in recvs if i != me for _, rng in bl)
+        loop = self.loopback
+        n_recv = sum(self._numel(rng) for i, bl in recvs if i != me or loop for _, rng in bl)
         sendbuf = self._buf("send", n_send, slab)
         recvbuf = self._buf("recv", n_recv, slab)
         sa = plan.parts[A][me][0]
@@ -300,19 +314,19 @@ class SlabEngine:
         # 2. one batched group of point-to-point messages: every pair at once
         roff, recv_regions = 0, {}
         for i, bl in recvs:
-            if i == me:
+            if i == me and not loop:
                 continue
             n = sum(self._numel(rng) for _, rng in bl)
             recv_regions[i] = (roff, roff + n)
             roff += n
         with self._phase("exchange", slab):
-            if dist is not None and plan.world > 1:
+            if dist is not None and (plan.world > 1 or loop):
                 self._p2p([(recvbuf[lo:hi], i) for i, (lo, hi) in recv_regions.items() if hi > lo],
-                          [(sendbuf[lo:hi], j) for j, (lo, hi) in send_regions.items() if j != me and hi > lo])
+                          [(sendbuf[lo:hi], j) for j, (lo, hi) in send_regions.items() if (j != me or loop) and hi > lo])
         # 3. unpack: row-contiguous strided copies into the stack (the local block straight from the send buffer)
         with self._phase("unpack", slab):
             for i, bl in recvs:
-                buf, off = (sendbuf, send_regions[me][0]) if i == me else (recvbuf, recv_regions[i][0])
+                buf, off = (sendbuf, send_regions[me][0]) if i == me and not loop else (recvbuf, recv_regions[i][0])
                 for p0, rng in bl:
                     shp = [rng[ax][1] - rng[ax][0] for ax in ob]
                     n = shp[0] * shp[1] * shp[2]
@@ -345,7 +359,7 @@ class SlabEngine:
         ntot = Z * Y * X
         flat = vol.reshape(-1)
         with self._phase("mean", vol):
-            if dist is None or plan.world == 1:
+            if dist is None or (plan.world == 1 and not self.loopback):
                 sums = np.asarray(self.backend.chunk_sums(flat), dtype=np.float32)
                 return np.float32(np.cumsum(sums, dtype=np.float32)[-1] / np.float32(ntot))
             starts = [s * Y * X for s, _ in plan.parts[0]] + [ntot]

@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     vol_path, out_path, sig, border, levels, winsize = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+    loopback = len(sys.argv) > 7 and sys.argv[7] == "loopback"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     import torch
     import torch.distributed as dist
@@ -33,14 +34,17 @@ def main():
     h.set_stream(torch.cuda.current_stream().cuda_stream)
     kernels = [None if s == "-" else _lib.gaussian_kernel(float(s)) for s in sig.split(",")]
     params = _lib.SweepParams(levels, winsize, 3, 5, 1.2, border, 1, 1)
-    eng = SlabEngine(plan, h, dist)
+    eng = SlabEngine(plan, h, dist, loopback=loopback)
     eng.filter_3d(slab, kernels, params)                      # a first step, so that the second reuses every buffer
     out = eng.filter_3d(slab, kernels, params).cpu().numpy()
     mean = eng.global_mean(slab)
+    full = eng.gather_z_slabs(torch.from_numpy(out).to(dev), 0)
     np.save(f"{out_path}.{rank}.npy", out)
     if rank == 0:
+        np.save(f"{out_path}.gathered.npy", full.cpu().numpy())
+    if rank == 0:
         np.save(f"{out_path}.mean.npy", np.float32(mean))
-        print("backend", dist.get_backend(), "phases", {k: round(v, 2) for k, v in eng.phase_times().items()}, flush=True)
+        print("backend", dist.get_backend(), "world", dist.get_world_size(), "phases", {k: round(v, 2) for k, v in eng.phase_times().items()}, flush=True)
     dist.barrier()
     dist.destroy_process_group()
     h.close()

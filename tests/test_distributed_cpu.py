@@ -38,7 +38,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, shape, sigmas, border_mode, use_of, q):
+def _worker(rank, world, port, shape, sigmas, border_mode, use_of, q, loopback=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -54,7 +54,7 @@ def _worker(rank, world, port, shape, sigmas, border_mode, use_of, q):
         slab = torch.from_numpy(vol[plan.z0:plan.z0 + plan.zlen].copy())
         kernels = [None if s is None else O.get_gaussian_kernel(s) for s in sigmas]
         params = _lib.SweepParams(0, 5, 3, 5, 1.2, border_mode, 1, int(use_of))
-        eng = SlabEngine(plan, OracleBackend(O), dist)
+        eng = SlabEngine(plan, OracleBackend(O), dist, loopback=loopback)
         mean_auto = eng.global_mean(slab)
         first = eng.filter_3d(slab, kernels, params, mean=vol.mean()).clone()
         out = eng.filter_3d(slab, kernels, params, mean=vol.mean())      # second step: the persistent buffers are reused
@@ -67,12 +67,12 @@ def _worker(rank, world, port, shape, sigmas, border_mode, use_of, q):
         dist.destroy_process_group()
 
 
-def _run(world, shape, sigmas, border_mode=0, use_of=True):
+def _run(world, shape, sigmas, border_mode=0, use_of=True, loopback=False):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, sigmas, border_mode, use_of, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, sigmas, border_mode, use_of, q, loopback)) for r in range(world)]
     for p in procs:
         p.start()
     res = q.get(timeout=240)
@@ -121,6 +121,20 @@ def test_sharded_no_of(oracle):
     vol = make_volume(shape, seed=21, amplitude=100.0)
     want = oracle.no_OF_filter(vol, [oracle.get_gaussian_kernel(s) for s in sig])
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("world,shape,border", [(1, (6, 34, 36), 0), (1, (3, 64, 128), 1), (2, (7, 34, 36), 0)])
+def test_loopback_routes_own_blocks_through_the_transport(oracle, world, shape, border):
+    """SlabEngine(loopback=True): the blocks a rank keeps are sent to itself inside the batched group and the mean
+    goes through the all_gather even with ONE rank -- the mode the GPU suite uses to put real RCCL calls under a
+    world-size-1 run (tests/test_gpu_full.py::test_rccl_world_size_1_carries_the_slab_engine).  Same bits."""
+    from flowdenoising_amd.synth import make_volume
+    sig = (1.0, 0.5, 1.0)
+    got, mean_auto = _run(world, shape, sig, border_mode=border, loopback=True)
+    vol = make_volume(shape, seed=21, amplitude=100.0)
+    want = oracle.OF_filter(vol, [oracle.get_gaussian_kernel(s) for s in sig], 0, 5, border_mode=border)
+    assert np.array_equal(got, want)
+    assert np.float32(mean_auto) == vol.mean()
 
 
 def test_exchange_schedule_is_consistent():

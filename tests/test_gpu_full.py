@@ -153,6 +153,47 @@ def test_slab_engine_on_hip_backend_multi_rank(fdn, tmp_path, world, shape, sig,
     assert np.load(f"{tmp_path}/o.mean.npy") == vol.mean()
 
 
+def test_rccl_world_size_1_carries_the_slab_engine(fdn, tmp_path):
+    """One real RCCL communicator on the one GPU every box has: a world-size-1 `nccl` process group carries the slab
+    engine in loopback mode -- the blocks of every exchange travel as send-to-self messages inside the batched group
+    (ncclSend / ncclRecv under ncclGroupStart / End, exactly the calls of an N > 1 run), the mean goes through
+    all_gather -- and the result equals the single-GPU OF_filter bit for bit."""
+    import socket
+    vol = _vol((12, 70, 150), seed=35)
+    np.save(tmp_path / "v.npy", vol)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {**os.environ, "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
+    sig = "1.0,0.5,1.0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_dist_hip_worker.py"), str(tmp_path / "v.npy"), str(tmp_path / "o"),
+                        sig, "0", "0", "5", "loopback"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    print(r.stdout.strip())
+    assert "backend nccl world 1" in r.stdout
+    ks = [fdn.get_gaussian_kernel(float(s)) for s in sig.split(",")]
+    want = fdn.OF_filter(vol, ks, 0, 5)
+    assert np.array_equal(np.load(f"{tmp_path}/o.0.npy"), want)
+    assert np.array_equal(np.load(f"{tmp_path}/o.gathered.npy"), want)
+    assert np.load(f"{tmp_path}/o.mean.npy") == vol.mean()
+
+
+def test_bench_gpus_2_from_a_bare_shell(fdn):
+    """`python3 bench.py --gpus 2 ...` the way the driver calls it (no torch.distributed.run around it): bench.py starts
+    its ranks as a child process, relays rank 0's line and exits with the child's code.  On a one-GPU box the two ranks
+    share GPU 0 (a rehearsal, labelled so); on a node with two GPUs the same command runs over RCCL."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shape", "24,96,160", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["backend"] in ("nccl", "gloo") and d["value"] > 0
+    assert len(d["phase_ms_per_step_per_rank"]["compute"]) == 2
+
+
 @pytest.mark.parametrize("l,w", [(0, 5), (1, 5), (0, 15)])
 def test_workspace_limit_bounds_every_buffer(fdn, oracle, l, w):
     """fdn_set_workspace_limit caps everything the handle owns (stack, re-oriented pass output, intermediate volumes,
