@@ -7,6 +7,14 @@
 namespace fdn {
 
 static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// clamp(v, 0, hi) for a wave-uniform hi >= 0 as ONE instruction: the compiler turns the compare/select form into
+// v_cmp + v_min + v_cndmask (it forms v_med3_i32 only for two constants); hot paths of the Farneback kernels only.
+static __device__ __forceinline__ int clamp0u(int v, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "s"(hi));
+    return r;
+}
 static __device__ __forceinline__ int reflect101(int p, int len)
 {
     if (len == 1) return 0;
@@ -111,7 +119,7 @@ struct GatherTapsP {
 // finish_M_p): two 16-byte and one 8-byte load per row.  Needs H >= 2, W >= 2, H, W < 2^24.
 static __device__ __forceinline__ void gather_R1_p(const RImage& R1, int H, int W, int x1, int y1, GatherTapsP& g)
 {
-    const unsigned px = __umul24((unsigned)clampi(y1, 0, H - 2), (unsigned)W) + (unsigned)clampi(x1, 0, W - 2);
+    const unsigned px = __umul24((unsigned)clamp0u(y1, H - 2), (unsigned)W) + (unsigned)clamp0u(x1, W - 2);
     const unsigned px1 = px + (unsigned)W;
     fdn_v4f t;
     t = ld_off_v4a8(R1.p01, px * 8u);  g.a0[0] = t.xy; g.b0[0] = t.zw;
@@ -131,6 +139,24 @@ static __device__ __forceinline__ void flow_target(float xf, float yf, float dx,
     fx -= flx; fy -= fly;
 }
 
+// (w.x v.x, w.x v.y) and (w.y v.x, w.y v.y): a weight held in one half of a register pair times a channel pair, the
+// broadcast done by the instruction's operand selects (the compiler splats such a weight with two v_mov_b32 first)
+#ifndef FDN_PK_OPSEL
+#define FDN_PK_OPSEL 0
+#endif
+static __device__ __forceinline__ fdn_v2f pk_mul_lo(fdn_v2f w, fdn_v2f v)
+{
+    fdn_v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(w), "v"(v));
+    return r;
+}
+static __device__ __forceinline__ fdn_v2f pk_mul_hi(fdn_v2f w, fdn_v2f v)
+{
+    fdn_v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(w), "v"(v));
+    return r;
+}
+
 // FarnebackUpdateMatrices for one pixel from its operands: (r01, r23, r4c) = R0 at the pixel, g = the
 // neighbour expansion's 2 x 2 footprint at (x1, y1) = floor(p + flow), (fx, fy) the fractions (exact f32
 // weights, no quantisation), (dx, dy) the flow.  The gather ran at a clamped position; the
@@ -146,8 +172,14 @@ static __device__ __forceinline__ void finish_M_p(fdn_v2f r01, fdn_v2f r23, floa
     // v_pk_mul_f32 with op_sel by hand removes 18 of the fused kernel's 734 instructions per row and changes nothing
     // measurable: 17.1 -> 17.2 ms)
     const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+#if FDN_PK_OPSEL
+    const fdn_v2f w0 = {a00, a01}, w1 = {a10, a11};
+    const fdn_v2f s01 = pk_mul_lo(w0, g.a0[0]) + pk_mul_hi(w0, g.b0[0]) + pk_mul_lo(w1, g.a1[0]) + pk_mul_hi(w1, g.b1[0]);
+    const fdn_v2f s23 = pk_mul_lo(w0, g.a0[1]) + pk_mul_hi(w0, g.b0[1]) + pk_mul_lo(w1, g.a1[1]) + pk_mul_hi(w1, g.b1[1]);
+#else
     const fdn_v2f s01 = a00 * g.a0[0] + a01 * g.b0[0] + a10 * g.a1[0] + a11 * g.b1[0];
     const fdn_v2f s23 = a00 * g.a0[1] + a01 * g.b0[1] + a10 * g.a1[1] + a11 * g.b1[1];
+#endif
     const float s4 = a00 * g.a0s + a01 * g.b0s + a10 * g.a1s + a11 * g.b1s;
     const fdn_v2f zero = {0.f, 0.f};
     fdn_v2f r23v = inside ? s01 : zero;                       // (r2, r3)
@@ -188,10 +220,27 @@ static __device__ __forceinline__ void compute_M(const RImage& R0, const RImage&
     m[0] = m02.x; m[2] = m02.y; m[3] = m34.x; m[4] = m34.y;
 }
 
+// 1.0 / x, correctly rounded, for 2^-500 < |x| < 2^500 (here x = det + 1e-3 of f64 sums of f32 products: about
+// [1e-3, 1e80]).  The compiler's IEEE division is v_div_scale x2, v_rcp, four fma, v_mul, v_fma, v_div_fmas,
+// v_div_fixup = 11 instructions; in this range neither scaling nor fix-up does anything (the quotient estimate
+// 1.0 * y is y itself), which leaves the reciprocal estimate, two Newton steps and the final residual correction:
+// the same fma chain, the same bits, 7 instructions.  NaN stays NaN; x = inf gives NaN instead of 0 (such a
+// system has NaN flows in the reference as well: inf * 0).
+static __device__ __forceinline__ double reciprocal(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(e, y, y);
+}
+
 static __device__ __forceinline__ float2 solve_flow(const double a[5], double scale)
 {
     double g11 = a[0] * scale, g12 = a[1] * scale, g22 = a[2] * scale, h1 = a[3] * scale, h2 = a[4] * scale;
-    double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+    double idet = reciprocal(g11 * g22 - g12 * g12 + 1e-3);
     float2 f;
     f.x = (float)((g11 * h2 - g12 * h1) * idet);
     f.y = (float)((g22 * h1 - g12 * h2) * idet);
@@ -245,8 +294,8 @@ static __device__ __forceinline__ void remap_issue(const float* __restrict__ src
     int sx = (int)qx, sy = (int)qy;
     r.ax = sx & 31; r.ay = sy & 31;
     int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);
-    int xa = clampi(ix, 0, W - 1), xb = clampi(ix + 1, 0, W - 1);
-    int ya = clampi(iy, 0, H - 1), yb = clampi(iy + 1, 0, H - 1);
+    int xa = clamp0u(ix, W - 1), xb = clamp0u(ix + 1, W - 1);
+    int ya = clamp0u(iy, H - 1), yb = clamp0u(iy + 1, H - 1);
     const unsigned oa = __umul24((unsigned)ya, (unsigned)W), ob = __umul24((unsigned)yb, (unsigned)W);   // H, W < 2^24
     if (PAIRS && W >= 2) {
         // the two taps of a row are neighbours except where the clamp folds them onto one pixel: one 8-byte load of the

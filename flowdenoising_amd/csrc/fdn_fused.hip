@@ -103,7 +103,16 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
 
     const int lane = threadIdx.x & 63;
     const int half = NB == 2 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;     // which of the workgroup's bands
-    const int stage = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
+#ifndef FDN_STAGE_MAP
+#define FDN_STAGE_MAP 1
+#endif
+    int stage_ = (threadIdx.x >> 6) & 3;
+    if (NB == 2 && FDN_STAGE_MAP) {
+        unsigned tab = 0x8DE4u;      // waves 0..7 -> stages A 1 2 3 | 1 3 A 2
+        if (FDN_STAGE_MAP == 2 && ((blockIdx.x >> 3) & 1)) tab = 0x3693u;   // 3 A 1 2 | 2 1 3 A
+        stage_ = (tab >> (2 * (threadIdx.x >> 6))) & 3;
+    }
+    const int stage = __builtin_amdgcn_readfirstlane(stage_);
     float (*Mx)[2][5][64] = MxAll[half];
     float* const win = win_all + (size_t)half * NRP * 5 * WCP;
     // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so giving XCD j the
@@ -131,12 +140,14 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
     const bool xdamp = border_test(xc, W);
     const int xw0 = xb - DX;                     // image column of window column 0
 
-    // Lanes the horizontal window of this lane reads: the lane that owns column clamp(x+j).
-    // (Replica lanes outside the image are never read: a replica's own window is shifted, so
-    // from the second iteration on it would no longer equal the border column it stands for.)
-    int src[2 * MH + 1];
-#pragma unroll
-    for (int j = -MH; j <= MH; j++) src[j + MH] = clampi(clampi(x + j, 0, W - 1) - xb, 0, 63);
+    // BORDER_REPLICATE of the box filter without a second code path: a lane outside the image takes every matrix
+    // row over from the hand-over slot of the lane that owns the border column (hl), so its running sums ARE the
+    // border column's and the lane shifts of the window sum deliver them to the border lanes' windows.  (Its own
+    // results are never used: its window is shifted, so from the second iteration on what it computes is not the
+    // border column's matrix -- which is why it must not feed its own rows back.)  Until round 3 bands touching an
+    // image edge summed their windows with ds_bpermute from clamped source lanes: 120 of them per row step, 24
+    // cycles each on the CU's one LDS pipe -- two bands of twenty ate two thirds of all LDS cycles.
+    const int hl = clampi(xc - xb, 0, 63);
 
     auto row_factor = [&](int y, float& by0, float& by1) {
         by0 = y < 5 ? (y < 2 ? 0.14f : 0.4472f) : 1.f;
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
     // Bilinear taps for a stage working on row ys.  `need`: lanes whose result is used.  Fast path:
     // the lane's 2x2 footprint lies in window rows [ys-D, ys+D] and the window's columns.
     auto gather = [&](int ys, int x1, int y1, bool need, GatherTapsP& g) __attribute__((always_inline)) {
-        const int x1c = clampi(x1, 0, W - 2), y1c = clampi(y1, 0, H - 2);
+        const int x1c = clamp0u(x1, W - 2), y1c = clamp0u(y1, H - 2);
         int col = x1c - xw0;
         int dy = y1c - (ys - D);
         const bool inwin = (unsigned)col <= (unsigned)(WC - 2) && (unsigned)dy <= (unsigned)(2 * D - 1);
@@ -168,9 +179,7 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
         }
         g.a0s = q0[4 * WCP - col]; g.b0s = q0[4 * WCP - col + 1];
         g.a1s = q1[4 * WCP - col]; g.b1s = q1[4 * WCP - col + 1];
-        if (__any(miss)) {       // a flow that leaves the window: those lanes (only) go to global memory
-            if (miss) gather_R1_p(R1i, H, W, x1, y1, g);
-        }
+        if (miss) gather_R1_p(R1i, H, W, x1, y1, g);   // a flow that leaves the window: those lanes (only) go to global memory (skipped by an execz branch)
     };
     const float xf = (float)xc;
     struct R0Px { fdn_v2f r01, r23; float r4; };     // R0 at one pixel
@@ -250,18 +259,15 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
     }
 
     // ===== waves 1..3: iteration `stage` =============================================================
-    // The loop is instantiated per stage and per band kind (K and EDGE are compile-time inside it) so
-    // that a row step of the common interior band is one basic block: the five channels' running-sum
-    // -> DPP -> f64-add chains then interleave instead of running one after the other.
-    const bool edge_band = xb < MH || xb + 63 + MH > W - 1;   // a window column of some lane is outside the image
+    // The loop is instantiated per stage (K is compile-time inside it) so that a row step is one basic block: the
+    // five channels' running-sum -> DPP -> f64-add chains then interleave instead of running one after the other.
     const bool owner = live && lane >= HALO && lane < 64 - HALO && x < W;
     const float* img1 = ACC ? uniform_ptr(stack + (size_t)(pb.t0 + b + pb.d) * HW) : nullptr;
     float2* flow_out = flow_out_base ? uniform_ptr((float2*)flow_out_base + (size_t)b * HW) : nullptr;
     float* acc = ACC ? uniform_ptr(acc_base + (size_t)b * HW) : nullptr;
 
-    auto stage_loop = [&](auto KT, auto ET) __attribute__((always_inline)) {
+    auto stage_loop = [&](auto KT) __attribute__((always_inline)) {
         constexpr int K = decltype(KT)::value;
-        constexpr bool EDGE = decltype(ET)::value;
         float (*Min)[5][64] = Mx[K - 1];
         const bool need = in_img && lane >= K * MH && lane < 64 - K * MH;   // lanes whose M_K feeds a valid output
         double vs[5];
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
         for (; t < K * STEP - MH; t++) lds_barrier();          // row 0 of M_{K-1} not yet produced
 #pragma unroll
         for (int c = 0; c < 5; c++) {                          // step K STEP - MH: n = 0
-            const float m = Min[0][c][lane];
+            const float m = Min[0][c][hl];
 #pragma unroll
             for (int i = 0; i < NE; i++) e[i][c] = m;
             vs[c] = 0.;
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
                 {
                     if (n <= H - 1) {          // take over the row the producer wrote in the previous step
 #pragma unroll
-                        for (int c = 0; c < 5; c++) e[at(0)][c] = Min[n & 1][c][lane];
+                        for (int c = 0; c < 5; c++) e[at(0)][c] = Min[n & 1][c][hl];
                     } else {                   // below the image: row H-1 again
 #pragma unroll
                         for (int c = 0; c < 5; c++) e[at(0)][c] = e[at(1)][c];
@@ -317,23 +323,17 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
                         vs[c] += (double)(e[at(0)][c] - e[at(RSD - 1)][c]);
-                        double s;     // the 2 MH + 1 terms left to right, starting from the first
-                        if (EDGE) {   // windows reach outside the image: read the lane of the clamped column
-                            s = __shfl(vs[c], src[0], 64);
+                        double s;     // the 2 MH + 1 terms left to right, starting from the first, by lane shifts
+                        double lft[MH], rgt[MH];
+                        lft[0] = wave_shr1(vs[c]); rgt[0] = wave_shl1(vs[c]);
 #pragma unroll
-                            for (int j = 1; j <= 2 * MH; j++) s += j == MH ? vs[c] : __shfl(vs[c], src[j], 64);
-                        } else {      // the same terms in the same order, by lane shifts
-                            double lft[MH], rgt[MH];
-                            lft[0] = wave_shr1(vs[c]); rgt[0] = wave_shl1(vs[c]);
+                        for (int i = 1; i < MH; i++) { lft[i] = wave_shr1(lft[i - 1]); rgt[i] = wave_shl1(rgt[i - 1]); }
+                        s = lft[MH - 1];
 #pragma unroll
-                            for (int i = 1; i < MH; i++) { lft[i] = wave_shr1(lft[i - 1]); rgt[i] = wave_shl1(rgt[i - 1]); }
-                            s = lft[MH - 1];
+                        for (int i = MH - 2; i >= 0; i--) s += lft[i];
+                        s += vs[c];
 #pragma unroll
-                            for (int i = MH - 2; i >= 0; i--) s += lft[i];
-                            s += vs[c];
-#pragma unroll
-                            for (int i = 0; i < MH; i++) s += rgt[i];
-                        }
+                        for (int i = 0; i < MH; i++) s += rgt[i];
                         a[c] = s;
                     }
                     const float2 f = solve_flow(a, scale);
@@ -378,9 +378,9 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
         }
     };
     using std::integral_constant;
-    if (stage == 1) { if (edge_band) stage_loop(integral_constant<int, 1>{}, integral_constant<bool, true>{}); else stage_loop(integral_constant<int, 1>{}, integral_constant<bool, false>{}); }
-    else if (stage == 2) { if (edge_band) stage_loop(integral_constant<int, 2>{}, integral_constant<bool, true>{}); else stage_loop(integral_constant<int, 2>{}, integral_constant<bool, false>{}); }
-    else { if (edge_band) stage_loop(integral_constant<int, 3>{}, integral_constant<bool, true>{}); else stage_loop(integral_constant<int, 3>{}, integral_constant<bool, false>{}); }
+    if (stage == 1) stage_loop(integral_constant<int, 1>{});
+    else if (stage == 2) stage_loop(integral_constant<int, 2>{});
+    else stage_loop(integral_constant<int, 3>{});
 }
 
 bool fused_supported(int winsize, int iters, int H, int W)
