@@ -1003,7 +1003,7 @@ FDN_API int fdn_set_option(fdn_handle h, const char* name, long value)
     FDN_HIP(hipStreamSynchronize(h->stream));
     if (!strcmp(name, "strict_order")) h->tn.strict_order = value != 0;
     else if (!strcmp(name, "path")) { if (value < 0 || value > 2) return fail("path must be 0 (auto), 1 (staged) or 2 (per-iteration kernels)"); h->tn.path = (int)value; }
-    else if (!strcmp(name, "fused_occ")) { if (value && (value < 3 || value > 5)) return fail("fused_occ must be 0, 3, 4 or 5"); h->tn.fused_occ = (int)value; }
+    else if (!strcmp(name, "fused_occ")) { if (value && (value < 3 || value > 5) && value != 8) return fail("fused_occ must be 0, 3, 4, 5 or 8"); h->tn.fused_occ = (int)value; }
     else if (!strcmp(name, "lds_pad")) { if (value < 0 || value > 160 * 1024) return fail("lds_pad out of range"); h->tn.lds_pad = (unsigned)value; }
     else return fail("unknown option '%s' (strict_order, path, fused_occ, lds_pad)", name);
     return 0;

@@ -103,6 +103,9 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
 
     const int lane = threadIdx.x & 63;
     const int half = NB == 2 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;     // which of the workgroup's bands
+#ifndef FDN_MASK_HALO
+#define FDN_MASK_HALO 1
+#endif
 #ifndef FDN_STAGE_MAP
 #define FDN_STAGE_MAP 1
 #endif
@@ -319,40 +322,47 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
                             vs[c] = v;
                         }
                     }
-                    double a[5];
+                    // running sums and their lane shifts on every lane (a halo lane's sums feed its neighbours' windows) ...
+                    double lft[5][MH], rgt[5][MH];
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
                         vs[c] += (double)(e[at(0)][c] - e[at(RSD - 1)][c]);
-                        double s;     // the 2 MH + 1 terms left to right, starting from the first, by lane shifts
-                        double lft[MH], rgt[MH];
-                        lft[0] = wave_shr1(vs[c]); rgt[0] = wave_shl1(vs[c]);
+                        lft[c][0] = wave_shr1(vs[c]); rgt[c][0] = wave_shl1(vs[c]);
 #pragma unroll
-                        for (int i = 1; i < MH; i++) { lft[i] = wave_shr1(lft[i - 1]); rgt[i] = wave_shl1(rgt[i - 1]); }
-                        s = lft[MH - 1];
-#pragma unroll
-                        for (int i = MH - 2; i >= 0; i--) s += lft[i];
-                        s += vs[c];
-#pragma unroll
-                        for (int i = 0; i < MH; i++) s += rgt[i];
-                        a[c] = s;
+                        for (int i = 1; i < MH; i++) { lft[c][i] = wave_shr1(lft[c][i - 1]); rgt[c][i] = wave_shl1(rgt[c][i - 1]); }
                     }
-                    const float2 f = solve_flow(a, scale);
-                    if (K < ITERS) {
-                        float mm[5];
-                        R0Px r0;
-                        load_R(R0i, o, r0.r01, r0.r23, r0.r4);
-                        update_matrices(y, f, r0, need, mm);
+                    // ... everything after that only on the lanes whose result is used (EXEC-masked: the part runs at the
+                    // clock its power budget allows, and idle lanes cost none: FDN_MASK_HALO = 0 for the A/B)
+                    if (!FDN_MASK_HALO || (K < ITERS ? need : owner)) {
+                        double a[5];
 #pragma unroll
-                        for (int c = 0; c < 5; c++) Mx[K < ITERS ? K : 0][y & 1][c][lane] = mm[c];
-                    } else if (ACC) {
-                        const float warped = remap_sample(img1, H, W, xc, y, f);
-                        const float acc_new = (float)((double)acc_old + (double)warped * weight);
-                        if (owner) {
-                            if (flow_out) st_off(flow_out, o * 8u, f);
-                            st_off(acc, o * 4u, acc_new);
+                        for (int c = 0; c < 5; c++) {
+                            double s = lft[c][MH - 1];     // the 2 MH + 1 terms left to right, starting from the first
+#pragma unroll
+                            for (int i = MH - 2; i >= 0; i--) s += lft[c][i];
+                            s += vs[c];
+#pragma unroll
+                            for (int i = 0; i < MH; i++) s += rgt[c][i];
+                            a[c] = s;
                         }
-                    } else if (owner) {      // a coarser pyramid level: the flow is the result
-                        st_off(flow_out, o * 8u, f);
+                        const float2 f = solve_flow(a, scale);
+                        if (K < ITERS) {
+                            float mm[5];
+                            R0Px r0;
+                            load_R(R0i, o, r0.r01, r0.r23, r0.r4);
+                            update_matrices(y, f, r0, need, mm);
+#pragma unroll
+                            for (int c = 0; c < 5; c++) Mx[K < ITERS ? K : 0][y & 1][c][lane] = mm[c];
+                        } else if (ACC) {
+                            const float warped = remap_sample(img1, H, W, xc, y, f);
+                            const float acc_new = (float)((double)acc_old + (double)warped * weight);
+                            if (owner) {
+                                if (flow_out) st_off(flow_out, o * 8u, f);
+                                st_off(acc, o * 4u, acc_new);
+                            }
+                        } else if (owner) {      // a coarser pyramid level: the flow is the result
+                            st_off(flow_out, o * 8u, f);
+                        }
                     }
                 }
             }
@@ -395,7 +405,16 @@ bool fused_supported(int winsize, int iters, int H, int W)
 // budget chosen for OCC workgroups per CU.  (ms per launch of 512 targets of 1024 x 1024 on MI355X.)
 template <int MH, int OCC> struct FusedVariant;
 template <> struct FusedVariant<2, 3> { static constexpr int D = 8, DX = 8, U = 3; };   // 47.0 KB [18.1]
-template <> struct FusedVariant<2, 4> { static constexpr int D = 7, DX = 5, U = 3; };   // 40.2 KB [17.2]
+#ifndef FDN_V24_D      // experiment switches of tools/build_variant.sh
+#define FDN_V24_D 7
+#endif
+#ifndef FDN_V24_DX
+#define FDN_V24_DX 5
+#endif
+#ifndef FDN_V24_U
+#define FDN_V24_U 3
+#endif
+template <> struct FusedVariant<2, 4> { static constexpr int D = FDN_V24_D, DX = FDN_V24_DX, U = FDN_V24_U; };   // 40.2 KB [17.2]
 template <> struct FusedVariant<2, 5> { static constexpr int D = 4, DX = 5, U = 1; };   // 31.4 KB, 96 VGPRs [18.0]
 template <> struct FusedVariant<1, 4> { static constexpr int D = 7, DX = 5, U = 2; };   // 58 useful columns per band
 template <> struct FusedVariant<3, 4> { static constexpr int D = 6, DX = 5, U = 4; };   // 46 useful columns per band
@@ -447,6 +466,7 @@ static void launch_variant(const float* Rstack, const float* stack, const float*
 static int choose_occupancy(long blocks, const Tuning& tn)
 {
     if (tn.fused_occ >= 3 && tn.fused_occ <= 5) return tn.fused_occ;
+    if (tn.fused_occ == 8) return 4;
     return blocks > (long)tn.cus * 4 && blocks <= (long)tn.cus * 5 ? 5 : 4;
 }
 
@@ -461,17 +481,20 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
     FlowSource fs{coarse_h, coarse_w, coarse_h > 0 ? (double)coarse_w / W : 1.0, coarse_h > 0 ? (double)coarse_h / H : 1.0};
     const double scale = 1. / ((double)winsize * winsize);
     const int mh = winsize / 2;
+#ifndef FDN_ONLY_MH2   // (experiment builds leave the other windows out: half the compile time)
     if (mh == 1) { launch_variant<1, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad); return; }
     if (mh == 3) { launch_variant<3, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad); return; }
     if (mh == 4) { launch_variant<4, 3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad); return; }
+#endif
     const int BW = 64 - 2 * 2 * 3;
     const long blocks = (long)((W + BW - 1) / BW) * pb.npairs;
     switch (choose_occupancy(blocks, tn)) {
     case 3: launch_variant<2, 3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad); break;
     case 5: launch_variant<2, 5>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad); break;
     default:
-        // large grids: two bands per workgroup (the same 4 bands per CU); tn.fused_occ = 4 asks for the one-band build
-        if (tn.fused_occ != 4 && blocks > (long)tn.cus * 5) launch_variant<2, 4, 2>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad);
+        // tn.fused_occ = 8: two bands per workgroup (the same 4 bands per CU, less HBM traffic; the default until the
+        // edge bands lost their ds_bpermute path -- since then one band per workgroup is 2 % faster on large grids too)
+        if (tn.fused_occ == 8) launch_variant<2, 4, 2>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad);
         else launch_variant<2, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad);
         break;
     }

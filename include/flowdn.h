@@ -99,8 +99,8 @@ int fdn_mem_info(fdn_handle h, size_t* free_out, size_t* total_out);
  *                       direct window sum (about 20x slower; errors out, never falls back, when a row does
  *                       not fit the LDS)
  *   "path"         0 automatic, 1 one kernel per Farneback stage, 2 one kernel per iteration
- *   "fused_occ"    0 automatic (large grids: two bands per 8-wave workgroup, two workgroups per CU), 3..5 one-band
- *                  workgroups per CU of the 3-iteration fused kernel
+ *   "fused_occ"    0 automatic, 3..5 one-band workgroups per CU of the 3-iteration fused kernel, 8 two bands per
+ *                  8-wave workgroup (two workgroups per CU)
  *   "lds_pad"      bytes of extra dynamic LDS per workgroup of that kernel (occupancy curves)
  * No counterpart in the reference (cv2 has no such switches). */
 int fdn_set_option(fdn_handle h, const char* name, long value);

@@ -150,9 +150,10 @@ def test_config4_full_volume(fdn, oracle):
     import bench
     from flowdenoising_amd import _lib
     from flowdenoising_amd.synth import make_volume
-    free, _total = torch.cuda.mem_get_info()
-    if free < 120 * 2**30:
-        pytest.skip("needs 120 GiB of free device memory")
+    free, total = torch.cuda.mem_get_info()
+    if total < 200 * 2**30:
+        pytest.skip("not an MI355X-class device (288 GB): configs[4] whole needs about 120 GiB")
+    assert free >= 120 * 2**30, f"only {free >> 30} GiB of {total >> 30} GiB free on the device: something else holds its memory"
     shape = (512, 2048, 2048)
     dev = torch.device("cuda", 0)
     vol = make_volume(shape, seed=1234 + 5, amplitude=100.0, xp=torch, device=dev)
@@ -169,3 +170,6 @@ def test_config4_full_volume(fdn, oracle):
     res = bench.check_output(h, vol, out, shape, kernels, params, mean)
     assert res["timed_output_equals_pass_by_pass_rerun"], res
     assert res["max_rel_err"] < TIGHT_TOL, res
+    # bit for bit against the oracle in OpenCV's own f64 summation order or, where a slice differs from that by the
+    # one re-associated sum of DESIGN.md 4.5, in the one-iteration kernel's block order (oracle box_mode 4)
+    assert res["bit_equal"] or res["bit_equal_kernel_order"], res

@@ -336,10 +336,10 @@ def test_strict_order_refuses_rows_it_cannot_hold(fdn):
         h.set_option("strict_order", 0)
 
 
-@pytest.mark.parametrize("env", [{}, {"FDN_FUSED_OCC": "3"}, {"FDN_FUSED_OCC": "5"}, {"FDN_FORCE_STAGED": "1"}, {"FDN_PATH": "2"}])
+@pytest.mark.parametrize("env", [{}, {"FDN_FUSED_OCC": "3"}, {"FDN_FUSED_OCC": "5"}, {"FDN_FUSED_OCC": "8"}, {"FDN_FORCE_STAGED": "1"}, {"FDN_PATH": "2"}])
 def test_kernel_variants_agree_bit_for_bit(fdn, oracle, tmp_path, env):
     """Every implementation of the chain step (the fused stage-pipelined kernel in its builds for 3, 4
-    and 5 workgroups per CU -- different LDS windows and unrolls -- the staged per-stage
+    and 5 workgroups per CU -- different LDS windows and unrolls --, its two-bands-per-workgroup build, the staged per-stage
     kernels and the one-iteration kernels) must give the oracle's bits on a multi-band image with interior and edge bands."""
     vol = _vol((10, 70, 300), seed=12)
     np.save(tmp_path / "v.npy", vol)
@@ -430,6 +430,27 @@ def test_wide_kernel_on_a_gib_volume_spot_parity(fdn, oracle):
         torch.cuda.empty_cache()
     want = oracle.filter_axis_range(sub, 0, k, 0, 5, mean, 16, 17, nthreads=16)
     assert np.array_equal(got, want[16])
+
+
+@pytest.mark.parametrize("axis,shape", [(1, (1024, 40, 1024)), (2, (1024, 1024, 40))])
+def test_wide_kernel_y_and_x_passes_spot_parity(fdn, oracle, axis, shape):
+    """BASELINE.json configs[3] has sigma = 4 on all three axes (K = 33, 33, 33): the Y and X passes on its
+    1024 x 1024 images (Z x X and Z x Y planes of the 1024^3 volume, seq:255 / seq:333), on stacks thin along the
+    pass's own axis; two target slices -- one whose chain reaches the mean padding, one with all 32 neighbours
+    inside -- against the oracle run on the sub-volume that feeds them."""
+    from flowdenoising_amd.synth import make_volume
+    vol = make_volume(shape, seed=1234 + 4, amplitude=100.0)
+    k = fdn.get_gaussian_kernel(4.0)
+    assert k.size == 33
+    mean = vol.mean()
+    fn = [fdn.OF_filter_along_Z, fdn.OF_filter_along_Y, fdn.OF_filter_along_X][axis]
+    got = fn(vol, k, 0, 5, mean)
+    n = shape[axis]
+    for t in (5, n // 2):
+        lo, hi = max(0, t - 16), min(n, t + 17)
+        sub = np.take(vol, range(lo, hi), axis=axis)
+        want = oracle.filter_axis_range(sub, axis, k, 0, 5, mean, t - lo, t - lo + 1, nthreads=16)
+        assert np.array_equal(np.take(got, [t], axis=axis), np.take(want, [t - lo], axis=axis))
 
 
 def test_non_finite_voxels_do_not_derail_the_kernels(fdn):
