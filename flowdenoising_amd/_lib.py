@@ -49,7 +49,7 @@ EXPORTS = [
     "fdn_memset_f32", "fdn_gaussian_kernel", "fdn_farneback", "fdn_farneback_strided", "fdn_farneback_dev",
     "fdn_warp", "fdn_warp_strided", "fdn_warp_dev", "fdn_farneback_typed", "fdn_warp_typed",
     "fdn_filter_axis_dev", "fdn_filter_axis", "fdn_filter_3d_dev", "fdn_filter_3d",
-    "fdn_mean_host", "fdn_mean_dev", "fdn_np_chunk_sums_dev", "fdn_sum_dev", "fdn_sweep_stack_dev", "fdn_permute_dev",
+    "fdn_mean_host", "fdn_mean_dev", "fdn_np_chunk_sums_dev", "fdn_sum_dev", "fdn_stats_dev", "fdn_convert_dev", "fdn_truncate_dev", "fdn_reserve_3d", "fdn_sweep_stack_dev", "fdn_permute_dev",
     "fdn_enable_timers", "fdn_get_timers", "fdn_add_timer", "fdn_version",
 ]
 
@@ -368,6 +368,12 @@ class Handle:
                                           ctypes.c_int(Y), ctypes.c_int(X), ptrs, Ks,
                                           ctypes.c_float(float(pad_value)), ctypes.byref(params)))
 
+    def reserve_3d(self, shape, Ks, params):
+        """Allocate what filter_3d_dev(shape, kernels of Ks taps, params) will use; launches nothing (fdn_reserve_3d)."""
+        Z, Y, X = shape
+        arr = (ctypes.c_int * 3)(*[int(k) for k in Ks])
+        check(self._lib.fdn_reserve_3d(self._h, ctypes.c_int(Z), ctypes.c_int(Y), ctypes.c_int(X), arr, ctypes.byref(params)))
+
     def filter_axis_dev(self, d_in, d_out, shape, axis, kernel, pad_value, params):
         Z, Y, X = shape
         kernel = np.ascontiguousarray(kernel, dtype=np.float64)
@@ -393,6 +399,25 @@ class Handle:
         m = ctypes.c_float()
         check(self._lib.fdn_mean_dev(self._h, ctypes.c_void_p(d_in), ctypes.c_size_t(int(count)), ctypes.byref(m)))
         return np.float32(m.value)
+
+    def stats_dev(self, d_in, count):
+        """{min, max, mean, std} of a device float32 array (float64 arithmetic): the MRC header statistics and the
+        volume statistics the reference logs (seq:529-532, 547-550, 562-564)."""
+        out = (ctypes.c_double * 4)()
+        check(self._lib.fdn_stats_dev(self._h, ctypes.c_void_p(d_in), ctypes.c_size_t(int(count)), out))
+        return {"min": out[0], "max": out[1], "mean": out[2], "std": out[3]}
+
+    def convert_dev(self, d_src, dtype, d_dst, count):
+        """d_dst (float32) = float32(d_src) for a device array of an 8- or 16-bit integer dtype."""
+        depth = DEPTHS[np.dtype(dtype).newbyteorder("=")]
+        check(self._lib.fdn_convert_dev(self._h, ctypes.c_void_p(d_src), ctypes.c_int(depth), ctypes.c_void_p(d_dst),
+                                        ctypes.c_size_t(int(count))))
+
+    def truncate_dev(self, d_src, dtype, d_dst, count):
+        """d_dst (uint8 / uint16) = d_src.astype(dtype) for a device float32 array (numpy's truncating cast, seq:566-571)."""
+        depth = DEPTHS[np.dtype(dtype)]
+        check(self._lib.fdn_truncate_dev(self._h, ctypes.c_void_p(d_src), ctypes.c_int(depth), ctypes.c_void_p(d_dst),
+                                         ctypes.c_size_t(int(count))))
 
     def np_chunk_sums_dev(self, d_in, count):
         """numpy's float32 pairwise sums of the 8192-element chunks of a device array (the last may be partial)."""

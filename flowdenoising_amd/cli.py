@@ -83,16 +83,44 @@ def _feedback(state):
         time.sleep(1)
 
 
-def _run_single(args, vol, kernels, l, w, device):
+def _run_single(args, vol, kernels, l, w, device, stats, as_float32, timing=None):
     from . import _lib
     from .operators import _params, filter_3d_own_mean
     border = _lib.BORDER_WRAP if args.compat == "par" else _lib.BORDER_MEAN_PAD
     params = _params(l, w, use_of=not args.no_OF, border_mode=border, chained=not args.recompute_flow)
     if args.chunk_slices:
         from .streaming import filter_streamed
+        if as_float32:
+            vol = vol.astype(np.float32)            # seq:517
         return filter_streamed(vol, kernels, l, w, None if args.chunk_slices < 0 else args.chunk_slices,
                                use_of=not args.no_OF, border_mode=border, chained=not args.recompute_flow, device=device)
-    return filter_3d_own_mean(vol, kernels, params, device)   # mean = vol.mean() (seq:420), taken on the GPU
+    # mean = vol.mean() (seq:420) and the statistics the reference logs / mrcfile writes: taken on the GPU
+    from . import io as fio
+    downcast = not fio.is_mrc_output(args.output) and args.compat != "par"     # seq:566-571's uint8 / uint16 TIFF, cast on the GPU
+    shape = vol.shape
+    tiff32 = args.compat == "par"
+
+    def sink(dtype, st_out):        # the output file, written slab by slab while the rest of the result is still downloading
+        stats["streamed"] = True
+        return fio.VolumeWriter(args.output, shape, np.float32 if (fio.is_mrc_output(args.output) or tiff32) else dtype, st_out)
+    return filter_3d_own_mean(vol, kernels, params, device, stats=stats, float32_semantics=as_float32, tiff_downcast=downcast,
+                              timing=timing, sink=sink)
+
+
+def _reserve(args, shape, dtype, Ks, l, w):
+    """While the file is being read: create the GPU context and allocate every buffer the filter will use
+    (fdn_reserve_3d) -- 25 GB of hipMalloc at configs[2], 0.4 s that would otherwise sit between upload and compute."""
+    try:
+        from . import _lib
+        from . import io as fio
+        from .operators import _params, handle, integer_semantics
+        border = _lib.BORDER_WRAP if args.compat == "par" else _lib.BORDER_MEAN_PAD
+        params = _params(l, w, use_of=not args.no_OF, border_mode=border, chained=not args.recompute_flow)
+        if fio.is_mrc_input(args.input):          # an integer MRC keeps its dtype (seq:513): other kernels, other buffers
+            params = integer_semantics(np.zeros((1, 1, 1), dtype=dtype), params)
+        handle(args.device).reserve_3d(shape, Ks, params)
+    except Exception as e:                        # an optimisation only: the real call reports real problems
+        logging.debug(f"reserve: {e}")
 
 
 def _run_sharded(args, shape, kernels, l, w):
@@ -193,14 +221,31 @@ def main(argv=None):
         shape, dtype = fio.volume_info(args.input)
         vol = None
     else:
+        prep = None
+        if not args.chunk_slices and not args.memory_map:
+            try:
+                hshape, hdtype = fio.volume_info(args.input)        # header / page directory only
+                Ks = [2 * int(4.0 * s + 0.5) + 1 for s in sigma[:3]]  # seq:30-41: taps of get_gaussian_kernel(sigma)
+                prep = threading.Thread(target=_reserve, args=(args, hshape, hdtype, Ks, l, w), daemon=True)
+                prep.start()
+            except Exception:
+                prep = None
         vol = fio.read_volume(args.input, mmap=args.memory_map)
-        if not fio.is_mrc_input(args.input):
-            vol = vol.astype(np.float32)            # seq:517, par:475: a TIFF is float32 from here on; an MRC keeps its dtype (seq:513)
-        shape, dtype = vol.shape, vol.dtype
-    logging.info(f"read \"{args.input}\" in {time.perf_counter() - t0} seconds")
+        if prep is not None:
+            prep.join()
+        # seq:517, par:475: a TIFF is float32 from here on; an MRC keeps its dtype (seq:513).  An 8- or 16-bit TIFF stack
+        # stays as read and is converted on the GPU (the same values, a quarter or half of the bytes on the host and the wire)
+        as_float32 = not fio.is_mrc_input(args.input)
+        if as_float32 and not (vol.dtype.kind in "iu" and vol.dtype.itemsize <= 2 and not args.chunk_slices):
+            vol = vol.astype(np.float32)
+        shape, dtype = vol.shape, (np.dtype(np.float32) if as_float32 else vol.dtype)
+    wall = {"read": time.perf_counter() - t0}      # phase record for tools/cli_wall.py (FDN_CLI_TIMING=<file>)
+    logging.info(f"read \"{args.input}\" in {wall['read']} seconds")
     logging.info(f"shape of the input volume (Z, Y, X) = {shape}")
     logging.info(f"type of the volume = {dtype}")
-    if vol is not None:
+    verbose = logging.getLogger().isEnabledFor(logging.INFO)       # seq:529-532 computes these eagerly; nobody reads them at -v 0
+    stats = {}
+    if vol is not None and verbose and args.chunk_slices:          # the streamed mode never holds the volume on the device
         logging.info(f"{args.input} max = {vol.max()}")
         logging.info(f"{args.input} min = {vol.min()}")
         logging.info(f"Input vol average = {vol.mean()}")
@@ -213,20 +258,36 @@ def main(argv=None):
     if sharded:
         filtered = _run_sharded(args, shape, kernels, l, w)
     else:
-        filtered = _run_single(args, vol, kernels, l, w, args.device)
-    logging.info(f"Volume filtered in {time.perf_counter() - t0} seconds")
+        filtered = _run_single(args, vol, kernels, l, w, args.device, stats, as_float32, timing=wall)
+    wall["filter"] = time.perf_counter() - t0
+    logging.info(f"Volume filtered in {wall['filter']} seconds")
     if rank != 0:
         return 0
+    if "in" in stats:            # seq:529-532, from the device copy
+        logging.info(f"{args.input} max = {stats['in']['max']}")
+        logging.info(f"{args.input} min = {stats['in']['min']}")
+        logging.info(f"Input vol average = {stats['in']['mean']}")
 
     logging.info(f"shape of the denoised volume (Z, Y, X) = {filtered.shape}")
     logging.info(f"{args.output} type = {filtered.dtype}")
-    logging.info(f"{args.output} max = {filtered.max()}")
-    logging.info(f"{args.output} min = {filtered.min()}")
-    logging.info(f"Output vol average = {filtered.mean()}")
+    if "out" in stats:           # seq:547-550
+        logging.info(f"{args.output} max = {stats['out']['max']}")
+        logging.info(f"{args.output} min = {stats['out']['min']}")
+        logging.info(f"Output vol average = {stats['out']['mean']}")
+    elif verbose:
+        logging.info(f"{args.output} max = {filtered.max()}")
+        logging.info(f"{args.output} min = {filtered.min()}")
+        logging.info(f"Output vol average = {filtered.mean()}")
     state["stage"] = "writing"
     t0 = time.perf_counter()
-    fio.write_volume(args.output, filtered, tiff_float32=(args.compat == "par"))
-    logging.info(f"written \"{args.output}\" in {time.perf_counter() - t0} seconds")
+    if not stats.get("streamed"):          # (the resident single-GPU path wrote the file while it downloaded the result)
+        fio.write_volume(args.output, filtered, tiff_float32=(args.compat == "par"), stats=stats.get("out"))
+    wall["write"] = time.perf_counter() - t0
+    logging.info(f"written \"{args.output}\" in {wall['write']} seconds")
+    if os.environ.get("FDN_CLI_TIMING"):
+        import json
+        with open(os.environ["FDN_CLI_TIMING"], "w") as f:
+            json.dump(wall, f)
     return 0
 
 

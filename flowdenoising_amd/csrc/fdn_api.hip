@@ -147,6 +147,7 @@ struct DevBuf {
 };
 
 struct fdn_ctx {
+    bool reserve_only = false;   // fdn_reserve_3d: size and allocate every buffer of a call, launch nothing
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -190,9 +191,11 @@ static void resolve_stamps(fdn_ctx* h)
 
 static int ensure(fdn_ctx* h, DevBuf& b, size_t bytes)
 {
-    // under a workspace limit a buffer is also given back when it is more than a quarter too large, so that what
-    // an earlier, differently shaped call left behind does not count against the limit for ever
-    if (b.cap >= bytes && !(h->ws_limit && b.cap > bytes + bytes / 4 + 4096)) return 0;
+    // under a workspace limit a buffer is also given back when it is more than a quarter (and more than 16 MB, or
+    // 1/256 of a smaller limit) too large, so that what an earlier, differently shaped call left behind does not count against the limit for ever.
+    // (The 16 MB keep the small buffers that one job asks for at alternating sizes -- reduction partials, the pair
+    // operators' scratch -- from being freed and reallocated, with a stream synchronisation, on every call.)
+    if (b.cap >= bytes && !(h->ws_limit && b.cap > bytes + bytes / 4 + std::min<size_t>((size_t)16 << 20, h->ws_limit >> 8))) return 0;
     if (b.p) {
         FDN_HIP(hipStreamSynchronize(h->stream));
         FDN_HIP(hipFree(b.p));
@@ -202,6 +205,12 @@ static int ensure(fdn_ctx* h, DevBuf& b, size_t bytes)
     if (e != hipSuccess) { b.p = nullptr; return fail("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
     b.cap = bytes;
     return 0;
+}
+
+static void release(DevBuf& b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.cap = 0;
 }
 
 static int ensure_pinned(fdn_ctx* h, size_t bytes)
@@ -411,6 +420,7 @@ static int build_R_pyramid(fdn_ctx* h, const float* imgs, int nimg, int H, int W
     const size_t tmp_cap = h->ws_limit ? (size_t)1 << 28 : (size_t)1 << 30;
     const int chunk = std::max(1, std::min(nimg, (int)(tmp_cap / (HW * 12))));
     if (ensure(h, h->pyr_tmp, (size_t)chunk * HW * 3 * sizeof(float))) return -1;
+    if (h->reserve_only) return 0;
     float* tmp = (float*)h->pyr_tmp.p;
     float* blurred = tmp + (size_t)chunk * HW;
     float* small = blurred + (size_t)chunk * HW;
@@ -600,6 +610,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
     const bool plain = wm_all.kind == FDN_WARP_F32;  // otherwise: flows from the Farneback kernels, folding by k_sweep_side
 
     if (!p->use_of) { // seq:184-185: taps in index order
+        if (h->reserve_only) return 0;
         ScopedTimer t(h, FDN_TIMER_WARP);
         launch_fill(out, 0.f, (size_t)S * HW, st);
         for (int i = 0; i < K; i++) launch_axpy_slices(stack, out, PairBatch{S, r, i - r}, H, W, kernel[i], st, wm_all);
@@ -624,6 +635,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
     const size_t flow_px = sweep_flow_px(path, r, pyramid);
     const size_t r_px = pyramid ? 27 : 20;
     const bool limited = h->ws_limit != 0;
+    bool rebuild_r = false;
     int C;
     if (limited) {
         const size_t other = owned_bytes(h) - (h->R.cap + h->Rpyr.cap + h->pyr_tmp.cap + h->flow.cap + h->M0.cap + h->M1.cap + h->flow_pyr.cap);
@@ -634,12 +646,32 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
                         "(%zu held by volumes and stacks)", h->ws_limit, W, H, K, other + fixed + per_target, other);
         C = (int)std::min<size_t>((size_t)S, (h->ws_limit - other - fixed) / per_target);
     } else {
+        // No limit: the expansions of the whole pass are the larger buffers and do not depend on C: they come first,
+        // and the flow batch is then sized from what is left after them (and after the pyramid's buffers, which
+        // build_R_pyramid allocates further down).  If not even the expansions fit next to one target's flows, R is
+        // rebuilt per batch as under a limit instead of failing in hipMalloc.
         size_t fre = 0, tot = 0;
         FDN_HIP(hipMemGetInfo(&fre, &tot));
-        size_t have = h->flow.cap + h->M0.cap + h->M1.cap;
-        C = (int)std::min<size_t>((size_t)S, std::max<size_t>(1, (fre + have) / 10 * 8 / (HW * flow_px)));
+        auto grow = [](const DevBuf& b, size_t want) { return want > b.cap ? want : (size_t)0; };     // bytes ensure() will newly claim (the old block is freed first)
+        const size_t r_all = (size_t)(S + 2 * r) * 5 * HW * sizeof(float);
+        const size_t pyr_all = pyramid ? (size_t)(S + 2 * r) * HW * 7 + std::min<size_t>((size_t)1 << 30, HW * 12 * (size_t)(S + 2 * r)) : 0;
+        const size_t pyr_have = h->Rpyr.cap + h->pyr_tmp.cap;
+        const size_t have = h->flow.cap + h->M0.cap + h->M1.cap + h->flow_pyr.cap;
+        const size_t avail = fre + have + h->R.cap + std::min(pyr_have, pyr_all);
+        const size_t need_r = r_all + pyr_all;
+        if (avail / 10 * 9 > need_r + HW * flow_px) {
+            C = (int)std::min<size_t>((size_t)S, std::max<size_t>(1, (avail - need_r) / 10 * 8 / (HW * flow_px)));
+            (void)grow;
+        } else {       // the expansions of the whole stack do not fit: batches of C targets with their own R
+            const size_t fixed = (size_t)2 * r * HW * r_px + (pyramid ? std::min<size_t>((size_t)1 << 30, HW * 12 * (size_t)(S + 2 * r)) : 0);
+            const size_t per_target = HW * (flow_px + r_px);
+            if (avail / 10 * 9 < fixed + per_target)
+                return fail("not enough device memory for a pass over %d x %d images with K = %d: %zu bytes free, %zu needed", W, H, K, avail, fixed + per_target);
+            C = (int)std::min<size_t>((size_t)S, (avail / 10 * 9 - fixed) / per_target);
+            rebuild_r = true;
+        }
     }
-    const int CR = limited ? C : S;              // target slices per rebuild of R
+    const int CR = limited || rebuild_r ? C : S;              // target slices per rebuild of R
     if (ensure(h, h->R, (size_t)(CR + 2 * r) * 5 * HW * sizeof(float))) return -1;
     float* R = (float*)h->R.p;
     if (fused || iter) {
@@ -650,6 +682,10 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
         if (ensure(h, h->M0, (size_t)C * HW * 20)) return -1;
         if (ensure(h, h->M1, (size_t)C * HW * 20)) return -1;
         if (pyramid && ensure_flow_pyramid(h, lv, C)) return -1;
+    }
+    if (h->reserve_only) {           // the pyramid's buffers as well, then done: nothing is launched
+        if (pyramid && build_R_pyramid(h, stack, std::min(CR, S) + 2 * r, H, W, lv, pc)) return -1;
+        return 0;
     }
     float* flow = (float*)h->flow.p;
     float* flowB = flow + (size_t)C * HW * 2; // fused / iter only
@@ -809,6 +845,11 @@ static int filter_axis_dev(fdn_ctx* h, const float* d_in, float* d_out, int Z, i
     if (ensure(h, h->stack, (size_t)(NP + 2 * r) * HW * sizeof(float))) return -1;
     float* stack = (float*)h->stack.p;
     if (axis != 0 && ensure(h, h->sweep_out, (size_t)NP * HW * sizeof(float))) return -1;
+    if (h->reserve_only) {
+        fdn_sweep_params pc = *p;
+        pc.pad_lo = pc.pad_hi = 0;
+        return sweep_stack(h, stack, stack, std::min(NP, S), H, W, kernel, K, &pc);
+    }
     for (int s0 = 0; s0 < S; s0 += NP) {
         const int np = std::min(NP, S - s0);
         {   // stack position q holds slice s0 - r + q: from the volume, wrapped (par:312), or the pad value (seq:88-89)
@@ -1064,14 +1105,22 @@ FDN_API int fdn_host_register(fdn_handle h, void* ptr, size_t bytes)
 {
     FDN_ENTER(h);
     if (!ptr || !bytes) return fail("NULL pointer");
-    FDN_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {      // a refusal is an answer, not a failure of the handle: callers fall back to pageable copies,
+        (void)hipGetLastError();   // so the runtime's sticky last-error must not surface in their next launch check
+        return fail("hipHostRegister(%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
     return 0;
 }
 FDN_API int fdn_host_unregister(fdn_handle h, void* ptr)
 {
     FDN_ENTER(h);
     if (!ptr) return fail("NULL pointer");
-    FDN_HIP(hipHostUnregister(ptr));
+    const hipError_t e = hipHostUnregister(ptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail("hipHostUnregister: %s", hipGetErrorString(e));
+    }
     return 0;
 }
 FDN_API int fdn_memset_f32(fdn_handle h, float* dst, float value, size_t count)
@@ -1433,6 +1482,10 @@ FDN_API int fdn_filter_3d(fdn_handle h, const float* in, float* out, int Z, int 
         FDN_HIP(hipMemcpyAsync(out, h->vol_out.p, bytes, hipMemcpyDeviceToHost, h->stream));
     }
     FDN_HIP(hipStreamSynchronize(h->stream));
+    // the two whole-volume device copies of a host-pointer call go back when they are large (2 x the volume on top of
+    // the pass's own buffers would otherwise stay with a process-wide handle: other handles, torch, ranks sharing the
+    // GPU need that memory); small volumes keep them, so that repeated calls do not allocate
+    if (bytes >= ((size_t)256 << 20)) { release(h->vol_in); release(h->vol_out); }
     return 0;
 }
 
@@ -1450,6 +1503,68 @@ FDN_API int fdn_sum_dev(fdn_handle h, const float* d_in, size_t count, double* s
     double s = 0;
     for (int i = 0; i < nb; i++) s += host[i];
     *sum_out = s;
+    return 0;
+}
+
+FDN_API int fdn_reserve_3d(fdn_handle h, int Z, int Y, int X, const int K[3], const fdn_sweep_params* p)
+{
+    FDN_ENTER(h);
+    if (!K) return fail("K is NULL");
+    if (Z <= 0 || Y <= 0 || X <= 0) return fail("bad volume dims");
+    if (K[0] <= 0 && K[1] <= 0 && K[2] <= 0) return 0;
+    static const double one = 1.0;
+    const double* kern[3] = {K[0] > 0 ? &one : nullptr, K[1] > 0 ? &one : nullptr, K[2] > 0 ? &one : nullptr};   // never read
+    float* const fake_in = (float*)(uintptr_t)16;    // never dereferenced: the sizing logic only compares them
+    float* const fake_out = (float*)(uintptr_t)32;
+    h->reserve_only = true;
+    const int rc = filter_3d_dev(h, fake_in, fake_out, Z, Y, X, kern, K, 0.f, p);
+    h->reserve_only = false;
+    return rc;
+}
+
+FDN_API int fdn_stats_dev(fdn_handle h, const float* d_in, size_t count, double* out4)
+{
+    FDN_ENTER(h);
+    if (!d_in || !out4) return fail("NULL pointer");
+    if (!count) return fail("empty volume");
+    const int MAXB = 4096;
+    if (ensure(h, h->partials, (size_t)MAXB * 4 * sizeof(double))) return -1;
+    std::vector<double> host((size_t)MAXB * 4);
+    double mn = 0, mx = 0, sum = 0, mean = 0, sq = 0;
+    for (int pass = 0; pass < 2; pass++) {          // pass 0: min, max, sum; pass 1: squared deviations from the mean
+        const int nb = launch_stats_partials(d_in, count, mean, (double*)h->partials.p, MAXB, h->stream);
+        FDN_HIP(hipGetLastError());
+        FDN_HIP(hipMemcpyAsync(host.data(), h->partials.p, (size_t)nb * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        FDN_HIP(hipStreamSynchronize(h->stream));
+        mn = host[0]; mx = host[1]; sum = 0; sq = 0;
+        for (int i = 0; i < nb; i++) {
+            mn = std::min(mn, host[4 * i]); mx = std::max(mx, host[4 * i + 1]);
+            sum += host[4 * i + 2]; sq += host[4 * i + 3];
+        }
+        mean = sum / (double)count;
+    }
+    out4[0] = mn; out4[1] = mx; out4[2] = mean; out4[3] = sqrt(sq / (double)count);
+    return 0;
+}
+
+FDN_API int fdn_convert_dev(fdn_handle h, const void* d_src, int depth, float* d_dst, size_t count)
+{
+    FDN_ENTER(h);
+    if (!d_src || !d_dst) return fail("NULL pointer");
+    if (depth != FDN_DEPTH_I16 && depth != FDN_DEPTH_U16 && depth != FDN_DEPTH_I8 && depth != FDN_DEPTH_U8)
+        return fail("fdn_convert_dev converts 8- and 16-bit integer volumes (depth %d)", depth);
+    launch_convert_f32(d_src, depth, d_dst, count, h->stream);
+    FDN_HIP(hipGetLastError());
+    return 0;
+}
+
+FDN_API int fdn_truncate_dev(fdn_handle h, const float* d_src, int depth, void* d_dst, size_t count)
+{
+    FDN_ENTER(h);
+    if (!d_src || !d_dst) return fail("NULL pointer");
+    if (depth != FDN_DEPTH_U16 && depth != FDN_DEPTH_U8) return fail("fdn_truncate_dev writes uint8 or uint16 (depth %d)", depth);
+    launch_truncate_from_f32(d_src, depth, d_dst, count, h->stream);
+    FDN_HIP(hipGetLastError());
     return 0;
 }
 

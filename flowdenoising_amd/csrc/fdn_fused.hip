@@ -94,9 +94,14 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
     constexpr int BW = 64 - 2 * HALO;
     constexpr int NRP = (ITERS - 1) * STEP + 2 * D + 2;   // window rows [t-2 STEP-D, t+D] + the one being loaded
     constexpr int WC = 64 + 2 * DX;               // D: window half-height (rows), DX: half-width (columns)
-    // window row = [ (c0,c1) x WCP ][ (c2,c3) x WCP ][ c4 x WCP ] floats (the RImage layout): pitch 5 WCP, kept
-    // even (8-byte aligned pairs) and away from multiples of 16 banks so that lanes reading different rows spread
-    constexpr int WCP = (5 * WC) % 16 == 0 ? WC + 2 : WC;
+#ifndef FDN_WIN_QUAD
+#define FDN_WIN_QUAD 1
+#endif
+    // FDN_WIN_QUAD (default): a window row is [ (c0,c1,c2,c3) x WC ] 16-byte pixels in one array and [ c4 x WC ] in a
+    // second one a quarter its size (so a pixel's c4 sits at a quarter of its quad's byte offset): the 2 x 2 footprint
+    // of four channels is four aligned ds_read_b128 (4 LDS cycles each, 64 banks) where the pair planes of the HBM
+    // layout took four ds_read2_b64 (8 cycles each, 32 banks).  0: the RImage layout, pitch 5 WCP floats.
+    constexpr int WCP = FDN_WIN_QUAD ? WC : (5 * WC) % 16 == 0 ? WC + 2 : WC;
     static_assert(WC % 2 == 0, "pair planes need an even pitch");
     __shared__ float MxAll[NB][ITERS][2][5][64]; // hand-over slots: row r of M_k lives in slot r & 1 for one step
     extern __shared__ __attribute__((aligned(16))) float win_all[];   // [NB][NRP][5 WCP] (dynamic: sized by the launcher)
@@ -118,6 +123,8 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
     const int stage = __builtin_amdgcn_readfirstlane(stage_);
     float (*Mx)[2][5][64] = MxAll[half];
     float* const win = win_all + (size_t)half * NRP * 5 * WCP;
+    char* const winq = (char*)win;                                  // quad array [NRP][WC] x 16 B
+    char* const win4 = (char*)win + (size_t)NRP * WC * 16;          // c4 array   [NRP][WC] x  4 B
     // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so giving XCD j the
     // j-th contiguous eighth of the (pair, band) list keeps the bands of a pair -- which share
     // their 12 halo columns and their rows in time -- behind one L2.  Speed only, never correctness.
@@ -172,16 +179,28 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
         s0 = min(s0, s0 - (unsigned)NRP);
         unsigned s1 = s0 + 1u;
         s1 = min(s1, s1 - (unsigned)NRP);
-        // (a, b) = columns (col, col + 1) of both channels of a pair: 16 contiguous bytes -> ds_read2_b64
-        const float* q0 = win + __umul24(s0, 5u * WCP) + 2 * col;
-        const float* q1 = win + __umul24(s1, 5u * WCP) + 2 * col;
+        if (FDN_WIN_QUAD) {
+            const unsigned o0 = __umul24(s0, 16u * WC) + 16u * (unsigned)col, o1 = __umul24(s1, 16u * WC) + 16u * (unsigned)col;
+            const fdn_v4f pa0 = *(const fdn_v4f*)(winq + o0), pb0 = *(const fdn_v4f*)(winq + o0 + 16);
+            const fdn_v4f pa1 = *(const fdn_v4f*)(winq + o1), pb1 = *(const fdn_v4f*)(winq + o1 + 16);
+            g.a0[0] = pa0.xy; g.a0[1] = pa0.zw; g.b0[0] = pb0.xy; g.b0[1] = pb0.zw;
+            g.a1[0] = pa1.xy; g.a1[1] = pa1.zw; g.b1[0] = pb1.xy; g.b1[1] = pb1.zw;
+            const float* c0 = (const float*)(win4 + (o0 >> 2));
+            const float* c1 = (const float*)(win4 + (o1 >> 2));
+            g.a0s = c0[0]; g.b0s = c0[1];
+            g.a1s = c1[0]; g.b1s = c1[1];
+        } else {
+            // (a, b) = columns (col, col + 1) of both channels of a pair: 16 contiguous bytes -> ds_read2_b64
+            const float* q0 = win + __umul24(s0, 5u * WCP) + 2 * col;
+            const float* q1 = win + __umul24(s1, 5u * WCP) + 2 * col;
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            g.a0[q] = *(const fdn_v2f*)(q0 + 2 * q * WCP); g.b0[q] = *(const fdn_v2f*)(q0 + 2 * q * WCP + 2);
-            g.a1[q] = *(const fdn_v2f*)(q1 + 2 * q * WCP); g.b1[q] = *(const fdn_v2f*)(q1 + 2 * q * WCP + 2);
+            for (int q = 0; q < 2; q++) {
+                g.a0[q] = *(const fdn_v2f*)(q0 + 2 * q * WCP); g.b0[q] = *(const fdn_v2f*)(q0 + 2 * q * WCP + 2);
+                g.a1[q] = *(const fdn_v2f*)(q1 + 2 * q * WCP); g.b1[q] = *(const fdn_v2f*)(q1 + 2 * q * WCP + 2);
+            }
+            g.a0s = q0[4 * WCP - col]; g.b0s = q0[4 * WCP - col + 1];
+            g.a1s = q1[4 * WCP - col]; g.b1s = q1[4 * WCP - col + 1];
         }
-        g.a0s = q0[4 * WCP - col]; g.b0s = q0[4 * WCP - col + 1];
-        g.a1s = q1[4 * WCP - col]; g.b1s = q1[4 * WCP - col + 1];
         if (miss) gather_R1_p(R1i, H, W, x1, y1, g);   // a flow that leaves the window: those lanes (only) go to global memory (skipped by an execz branch)
     };
     const float xf = (float)xc;
@@ -220,6 +239,18 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
             load_R(R1i, vo + wcol1, w.b01, w.b23, w.b4);
         };
         auto store_window_row = [&](int v, const WinRow& w) __attribute__((always_inline)) {
+            if (FDN_WIN_QUAD) {
+                const unsigned r = (unsigned)(v % NRP) * (16u * WC);
+                fdn_v4f qa; qa.xy = w.a01; qa.zw = w.a23;
+                *(fdn_v4f*)(winq + r + 16u * lane) = qa;
+                *(float*)(win4 + (r >> 2) + 4u * lane) = w.a4;
+                if (lane < 2 * DX) {
+                    fdn_v4f qb; qb.xy = w.b01; qb.zw = w.b23;
+                    *(fdn_v4f*)(winq + r + 16u * (64 + lane)) = qb;
+                    *(float*)(win4 + (r >> 2) + 4u * (64 + lane)) = w.b4;
+                }
+                return;
+            }
             float* row = win + (size_t)(v % NRP) * 5 * WCP;
             *(fdn_v2f*)(row + 2 * lane) = w.a01;
             *(fdn_v2f*)(row + 2 * WCP + 2 * lane) = w.a23;
@@ -425,7 +456,7 @@ static void launch_variant(const float* Rstack, const float* stack, const float*
                            PairBatch pb, int H, int W, double scale, double weight, FlowSource fs, hipStream_t st, unsigned lds_pad)
 {
     constexpr int D = FusedVariant<MH, OCC>::D, DX = FusedVariant<MH, OCC>::DX, U = FusedVariant<MH, OCC>::U;
-    constexpr int WC = 64 + 2 * DX, WCP = (5 * WC) % 16 == 0 ? WC + 2 : WC;   // as in the kernel
+    constexpr int WC = 64 + 2 * DX, WCP = FDN_WIN_QUAD ? WC : (5 * WC) % 16 == 0 ? WC + 2 : WC;   // as in the kernel
     constexpr unsigned win_bytes = (2 * (MH + 1) + 2 * D + 2) * 5 * WCP * sizeof(float);
     // a CU's 160 KB of LDS is handed out in 2 KB granules
     static_assert(win_bytes + 3 * 2 * 5 * 64 * sizeof(float) <= (160 * 1024 / OCC) / 2048 * 2048, "LDS per workgroup");

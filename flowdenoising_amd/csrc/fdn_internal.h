@@ -116,6 +116,9 @@ void launch_permute(const float* in, float* out, int A, int B, int C, int64_t sa
 // partial sums (f64) into `partials` (nblocks entries); returns nblocks used
 // sums[c] = numpy's float32 pairwise sum of in[8192 c .. 8192 c + 8191]
 void launch_np_chunk_sums(const float* in, size_t nchunks, float* sums, hipStream_t st);
+int launch_stats_partials(const float* in, size_t count, double centre, double* partials, int max_blocks, hipStream_t st);
+void launch_convert_f32(const void* in, int depth, float* out, size_t count, hipStream_t st);
+void launch_truncate_from_f32(const float* in, int depth, void* out, size_t count, hipStream_t st);
 int launch_sum_partials(const float* in, size_t count, double* partials, int max_blocks,
                         hipStream_t st);
 

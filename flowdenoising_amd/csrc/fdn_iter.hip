@@ -27,6 +27,13 @@
 // LDS per workgroup at winsize 15: 20.0 KB ring + 5.3 KB window rows = 25.3 KB -> 6 workgroups = 12 waves per CU.
 #include "fdn_internal.h"
 #include "fdn_device.h"
+#include <algorithm>
+#include <utility>
+#include <vector>
+
+#ifndef FDN_ITER_MASK
+#define FDN_ITER_MASK 1
+#endif
 
 namespace fdn {
 
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(ACC ? 192 : 128) void k_farneback_iter(const float*
         // dependent global gather whose latency would otherwise sit in the consumer's step (12.0 against 9.2 ms per launch).
         for (int t = 0; t < T; t++) {
             const int y = t - MH - 2;
-            if (y >= 0 && y < H) {
+            if (y >= 0 && y < H && (!FDN_ITER_MASK || owner)) {       // halo lanes idle (EXEC-masked): the launch runs at its power cap
                 const float2 f = fho[(y & 1) * 64 + lane];
                 const unsigned o = (unsigned)y * (unsigned)W + (unsigned)xc;
                 const float acc_old = ld_off<float>(acc, o * 4u);
@@ -237,25 +244,27 @@ __global__ __launch_bounds__(ACC ? 192 : 128) void k_farneback_iter(const float*
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                if (!FDN_ITER_MASK || owner) {      // the band's halo lanes stop here: their window sums feed nobody
 #pragma unroll
-                for (int c = 0; c < 5; c++) {
-                    const double* r1 = row1 + c * 64 + lane + MH;
-                    const double* r0 = row0 + c * 64 + lane + MH;
-                    double s = 0.;
-                    for (int bk = 0; bk < WQ; bk++) {
-                        const int off = -MH + WE + WP * bk;
-                        const double term = off == 0 ? blk[c] : r1[off];
-                        s = bk == 0 ? term : s + term;
+                    for (int c = 0; c < 5; c++) {
+                        const double* r1 = row1 + c * 64 + lane + MH;
+                        const double* r0 = row0 + c * 64 + lane + MH;
+                        double s = 0.;
+                        for (int bk = 0; bk < WQ; bk++) {
+                            const int off = -MH + WE + WP * bk;
+                            const double term = off == 0 ? blk[c] : r1[off];
+                            s = bk == 0 ? term : s + term;
+                        }
+                        for (int j = 0; j < WREM; j++) s += r0[MH - WREM + 1 + j];
+                        a[c] = s;
                     }
-                    for (int j = 0; j < WREM; j++) s += r0[MH - WREM + 1 + j];
-                    a[c] = s;
+                    const float2 f = solve_flow(a, scale);
+                    if (ACC) fho[(y & 1) * 64 + lane] = f;         // to the warper; this slot was last read two steps ago
+                    if (owner && flow_out) st_off(flow_out, o * 8u, f);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
-            const float2 f = solve_flow(a, scale);
-            if (ACC) fho[(y & 1) * 64 + lane] = f;         // to the warper; this slot was last read two steps ago
-            if (owner && flow_out) st_off(flow_out, o * 8u, f);
         }
         lds_barrier_iter();
     }
@@ -283,9 +292,19 @@ static int launch_iter_t(const float* Rstack, const float* stack, const float* f
     const size_t lds = iter_lds_bytes(mh, acc != nullptr);
     const int fin = !flow_in ? 0 : fs.h > 0 ? 2 : 1;
     auto launch = [&](auto kern) -> int {
-        if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        if (lds > 48 * 1024) {      // a kernel must be told (per device and host thread) that it may take that much dynamic LDS:
+            struct Told { const void* k; int dev; size_t bytes; };      // once per size it has not been granted yet
+            static thread_local std::vector<Told> told;
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            auto it = std::find_if(told.begin(), told.end(), [&](const Told& t) { return t.k == (const void*)kern && t.dev == dev; });
+            if (it == told.end() || it->bytes < lds) {
+                if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return -1; }
+                if (it == told.end()) told.push_back(Told{(const void*)kern, dev, lds}); else it->bytes = lds;
+            }
+        }
         hipLaunchKernelGGL(kern, grid, dim3(acc ? 192 : 128), lds, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, nbands, fs);
-        return 0;
+        return hipGetLastError() == hipSuccess ? 0 : -1;      // a bad launch configuration is this launch's error, not the next check's
     };
     if (acc) {
         if (fin == 2) return launch(k_farneback_iter<MHT, 2, true>);

@@ -12,6 +12,7 @@
 // Layouts: images [H][W] f32; polynomial expansion R: channel pairs (0,1), (2,3) interleaved +
 // channel 4 planar (RImage, fdn_device.h); matrices M: 5 planes of [H][W]; flow: interleaved
 // (x,y) float2 as in cv2.
+#include "../../include/flowdn.h"
 #include "fdn_internal.h"
 #include "fdn_device.h"
 
@@ -736,6 +737,99 @@ int launch_sum_partials(const float* in, size_t count, double* partials, int max
     if (g == 0) g = 1;
     hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)g), dim3(256), 0, st, in, count, partials);
     return (int)g;
+}
+
+// ---------------------------------------------------------------------------------
+// Header statistics of an output volume (what mrcfile's set_data / update_header_stats computes on the host for the
+// file seq:562-564 writes: dmin, dmax, dmean, rms) and the statistics seq:529-532 / 547-550 log: per block
+// {min, max, sum, sum of squared deviations from `centre`} in f64; two launches (the second with the mean as centre).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stats_partials(const float* __restrict__ in, size_t count, double centre, double* __restrict__ partials)
+{
+    __shared__ double sh[4][4];
+    double mn = __builtin_inf(), mx = -__builtin_inf(), s = 0, q = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        const double v = (double)in[i];
+        mn = v < mn ? v : mn; mx = v > mx ? v : mx;     // (a NaN voxel is skipped by both, as numpy's nanmin would; numpy's min propagates it)
+        s += v;
+        q += (v - centre) * (v - centre);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double a = __shfl_down(mn, off, 64), b = __shfl_down(mx, off, 64);
+        mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+        s += __shfl_down(s, off, 64); q += __shfl_down(q, off, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[w][0] = mn; sh[w][1] = mx; sh[w][2] = s; sh[w][3] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) {
+            sh[0][0] = sh[k][0] < sh[0][0] ? sh[k][0] : sh[0][0]; sh[0][1] = sh[k][1] > sh[0][1] ? sh[k][1] : sh[0][1];
+            sh[0][2] += sh[k][2]; sh[0][3] += sh[k][3];
+        }
+        for (int k = 0; k < 4; k++) partials[(size_t)blockIdx.x * 4 + k] = sh[0][k];
+    }
+}
+int launch_stats_partials(const float* in, size_t count, double centre, double* partials, int max_blocks, hipStream_t st)
+{
+    size_t g = (count + 255) / 256;
+    if (g > (size_t)max_blocks) g = max_blocks;
+    if (g == 0) g = 1;
+    hipLaunchKernelGGL(k_stats_partials, dim3((unsigned)g), dim3(256), 0, st, in, count, centre, partials);
+    return (int)g;
+}
+
+// float32(volume) of an integer volume on the device (seq:517's astype(np.float32) of a TIFF stack; the device copy
+// of an integer MRC): exact for 8- and 16-bit types.  16 bytes of source per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void k_convert_f32(const T* __restrict__ in, float* __restrict__ out, size_t count)
+{
+    constexpr int N = 16 / sizeof(T);
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * N;
+    if (i0 + N <= count && ((uintptr_t)in & 15) == 0) {
+        const uint4 raw = *(const uint4*)(in + i0);
+        const T* v = (const T*)&raw;
+#pragma unroll
+        for (int k = 0; k < N; k++) out[i0 + k] = (float)v[k];
+    } else {
+        for (size_t i = i0; i < count && i < i0 + N; i++) out[i] = (float)in[i];
+    }
+}
+void launch_convert_f32(const void* in, int depth, float* out, size_t count, hipStream_t st)
+{
+    if (!count) return;
+    auto go = [&](auto tag) {
+        using T = decltype(tag);
+        constexpr int N = 16 / sizeof(T);
+        hipLaunchKernelGGL(k_convert_f32<T>, dim3((unsigned)((count + 256 * N - 1) / (256 * N))), dim3(256), 0, st, (const T*)in, out, count);
+    };
+    switch (depth) {
+    case FDN_DEPTH_I16: go((int16_t)0); break;
+    case FDN_DEPTH_U16: go((uint16_t)0); break;
+    case FDN_DEPTH_I8: go((int8_t)0); break;
+    case FDN_DEPTH_U8: go((uint8_t)0); break;
+    default: break;
+    }
+}
+
+// numpy's `filtered.astype(np.uint8 / np.uint16)` (seq:566-571: the TIFF output) on the device: C's float -> integer
+// cast as x86 compilers emit it for the narrow types: truncate toward zero to a 32-bit integer, keep the low bits
+// (a slightly negative voxel wraps to 65535 exactly as in the reference; NaN and |v| >= 2^31 are undefined there).
+template <typename T>
+__global__ __launch_bounds__(256) void k_truncate_from_f32(const float* __restrict__ in, T* __restrict__ out, size_t count)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        const float v = in[i];
+        const int iv = v != v ? (int)0x80000000 : (v >= 2147483648.f || v < -2147483648.f) ? (int)0x80000000 : (int)v;   // cvttss2si
+        out[i] = (T)(unsigned)iv;
+    }
+}
+void launch_truncate_from_f32(const float* in, int depth, void* out, size_t count, hipStream_t st)
+{
+    if (!count) return;
+    const unsigned g = (unsigned)std::min<size_t>((count + 255) / 256, 65536);
+    if (depth == FDN_DEPTH_U16) hipLaunchKernelGGL(k_truncate_from_f32<uint16_t>, dim3(g), dim3(256), 0, st, in, (uint16_t*)out, count);
+    else if (depth == FDN_DEPTH_U8) hipLaunchKernelGGL(k_truncate_from_f32<uint8_t>, dim3(g), dim3(256), 0, st, in, (uint8_t*)out, count);
 }
 
 // ---------------------------------------------------------------------------------

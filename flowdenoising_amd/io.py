@@ -49,33 +49,43 @@ def read_mrc(path, mmap=False):
     return data.reshape(nz, ny, nx)
 
 
-def write_mrc(path, vol):
-    vol = np.ascontiguousarray(vol, dtype="<f4")
-    nz, ny, nx = vol.shape
+def _mrc_header(shape, stats):
+    nz, ny, nx = shape
     h = bytearray(1024)
     struct.pack_into("<10i", h, 0, nx, ny, nz, 2, 0, 0, 0, nx, ny, nz)
     struct.pack_into("<6f", h, 40, float(nx), float(ny), float(nz), 90.0, 90.0, 90.0)   # cella (1 A voxels), cellb
     struct.pack_into("<3i", h, 64, 1, 2, 3)                                             # mapc, mapr, maps
-    v64 = vol.astype(np.float64, copy=False) if vol.size < (1 << 27) else None
-    dmin, dmax = float(vol.min()), float(vol.max())
-    if v64 is not None:
-        dmean, rms = float(v64.mean()), float(v64.std())
-    else:  # slice-wise to bound memory
-        s = sum(float(z.sum(dtype=np.float64)) for z in vol)
-        dmean = s / vol.size
-        rms = float(np.sqrt(sum(float(((z.astype(np.float64) - dmean) ** 2).sum()) for z in vol) / vol.size))
-    struct.pack_into("<3f", h, 76, dmin, dmax, dmean)
+    struct.pack_into("<3f", h, 76, float(stats["min"]), float(stats["max"]), float(stats["mean"]))
     struct.pack_into("<i", h, 88, 1)            # ispg: a volume
     struct.pack_into("<i", h, 92, 0)            # nsymbt
     struct.pack_into("<i", h, 108, 20140)       # nversion
     h[208:212] = b"MAP "
     h[212:216] = bytes([0x44, 0x44, 0, 0])      # little-endian machine stamp
-    struct.pack_into("<f", h, 216, rms)
+    struct.pack_into("<f", h, 216, float(stats["std"]))
     label = b"flowdenoising_amd (MI355X)"
     struct.pack_into("<i", h, 220, 1)
     h[224:224 + len(label)] = label
+    return h
+
+
+def volume_stats(vol):
+    """min / max / mean / std (the MRC header's dmin, dmax, dmean, rms) of a host array, float64 arithmetic."""
+    vol = np.asarray(vol)
+    if vol.size < (1 << 27):
+        v64 = vol.astype(np.float64, copy=False)
+        return {"min": float(vol.min()), "max": float(vol.max()), "mean": float(v64.mean()), "std": float(v64.std())}
+    s = sum(float(z.sum(dtype=np.float64)) for z in vol)      # slice-wise to bound memory
+    mean = s / vol.size
+    var = sum(float(((z.astype(np.float64) - mean) ** 2).sum()) for z in vol) / vol.size
+    return {"min": float(vol.min()), "max": float(vol.max()), "mean": mean, "std": float(np.sqrt(var))}
+
+
+def write_mrc(path, vol, stats=None):
+    """stats: {"min", "max", "mean", "std"} of `vol` when the caller has them already (the CLI takes them on the GPU,
+    fdn_stats_dev); otherwise they are computed here."""
+    vol = np.ascontiguousarray(vol, dtype="<f4")
     with open(path, "wb") as f:
-        f.write(h)
+        f.write(_mrc_header(vol.shape, stats if stats is not None else volume_stats(vol)))
         vol.tofile(f)
 
 
@@ -199,62 +209,104 @@ def read_tiff(path, zrange=None, shape_only=False):
         return out
 
 
-def write_tiff(path, vol):
-    """One uncompressed strip and one IFD per page, little-endian; BigTIFF above 4 GiB."""
-    vol = np.ascontiguousarray(vol)
-    if vol.ndim == 2:
-        vol = vol[None]
-    kind = vol.dtype.kind
-    if kind not in "uif" or vol.dtype.itemsize not in (1, 2, 4, 8):
-        raise ValueError(f"cannot write dtype {vol.dtype} as TIFF")
-    vol = vol.astype(vol.dtype.newbyteorder("<"), copy=False)
-    Z, H, W = vol.shape
-    page_bytes = H * W * vol.dtype.itemsize
-    big = Z * (page_bytes + 512) + 1024 > (1 << 32) - (1 << 25)
-    fmt_code = {"u": 1, "i": 2, "f": 3}[kind]
-    desc = ('{"shape": [%d, %d, %d]}' % (Z, H, W)).encode() + b"\0"
-    with open(path, "wb") as f:
-        if big:
+class _TiffPages:
+    """Page after page of an uncompressed multi-page TIFF: one strip and one IFD per page, little-endian; BigTIFF above 4 GiB."""
+
+    def __init__(self, f, shape, dtype):
+        dtype = np.dtype(dtype)
+        kind = dtype.kind
+        if kind not in "uif" or dtype.itemsize not in (1, 2, 4, 8):
+            raise ValueError(f"cannot write dtype {dtype} as TIFF")
+        self.f, self.dtype = f, dtype.newbyteorder("<")
+        self.Z, self.H, self.W = shape
+        self.page_bytes = self.H * self.W * dtype.itemsize
+        self.big = self.Z * (self.page_bytes + 512) + 1024 > (1 << 32) - (1 << 25)
+        self.fmt_code = {"u": 1, "i": 2, "f": 3}[kind]
+        self.desc = ('{"shape": [%d, %d, %d]}' % (self.Z, self.H, self.W)).encode() + b"\0"
+        if self.big:
             f.write(b"II" + struct.pack("<HHHQ", 43, 8, 0, 16))
         else:
             f.write(b"II" + struct.pack("<HI", 42, 8))
-        pos = f.tell()
-        for z in range(Z):
-            entries = [(256, 4, W), (257, 4, H), (258, 3, vol.dtype.itemsize * 8), (259, 3, 1), (262, 3, 1)]
-            if z == 0:
-                entries.append((270, 2, desc))
-            entries += [(273, 16 if big else 4, None), (277, 3, 1), (278, 4, H), (279, 16 if big else 4, page_bytes),
-                        (339, 3, fmt_code)]
-            n = len(entries)
-            ifd_size = (8 + n * 20 + 8) if big else (2 + n * 12 + 4)
-            extra = len(desc) if z == 0 and len(desc) > (8 if big else 4) else 0
-            data_off = pos + ifd_size + extra
-            data_off += (-data_off) % 16
-            next_ifd = data_off + page_bytes if z + 1 < Z else 0
-            next_ifd += (-next_ifd) % 2
-            buf = bytearray(struct.pack("<Q" if big else "<H", n))
-            for tag, typ, val in entries:
-                if tag == 273:
-                    val = data_off
-                if typ == 2:
-                    cnt = len(val)
-                    if cnt > (8 if big else 4):
-                        field = struct.pack("<Q" if big else "<I", pos + ifd_size)
-                    else:
-                        field = val.ljust(8 if big else 4, b"\0")
+        self.pos = f.tell()
+        self.z = 0
+
+    def write_page(self, page):
+        f, big, z, Z, H, W, desc, page_bytes = self.f, self.big, self.z, self.Z, self.H, self.W, self.desc, self.page_bytes
+        pos = self.pos
+        entries = [(256, 4, W), (257, 4, H), (258, 3, self.dtype.itemsize * 8), (259, 3, 1), (262, 3, 1)]
+        if z == 0:
+            entries.append((270, 2, desc))
+        entries += [(273, 16 if big else 4, None), (277, 3, 1), (278, 4, H), (279, 16 if big else 4, page_bytes),
+                    (339, 3, self.fmt_code)]
+        n = len(entries)
+        ifd_size = (8 + n * 20 + 8) if big else (2 + n * 12 + 4)
+        extra = len(desc) if z == 0 and len(desc) > (8 if big else 4) else 0
+        data_off = pos + ifd_size + extra
+        data_off += (-data_off) % 16
+        next_ifd = data_off + page_bytes if z + 1 < Z else 0
+        next_ifd += (-next_ifd) % 2
+        buf = bytearray(struct.pack("<Q" if big else "<H", n))
+        for tag, typ, val in entries:
+            if tag == 273:
+                val = data_off
+            if typ == 2:
+                cnt = len(val)
+                if cnt > (8 if big else 4):
+                    field = struct.pack("<Q" if big else "<I", pos + ifd_size)
                 else:
-                    cnt = 1
-                    field = struct.pack("<" + {3: "H", 4: "I", 16: "Q"}[typ], val).ljust(8 if big else 4, b"\0")
-                buf += struct.pack("<HH", tag, typ) + struct.pack("<Q" if big else "<I", cnt) + field
-            buf += struct.pack("<Q" if big else "<I", next_ifd)
-            if extra:
-                buf += desc
-            f.seek(pos)
-            f.write(buf)
-            f.seek(data_off)
-            vol[z].tofile(f)
-            pos = next_ifd
+                    field = val.ljust(8 if big else 4, b"\0")
+            else:
+                cnt = 1
+                field = struct.pack("<" + {3: "H", 4: "I", 16: "Q"}[typ], val).ljust(8 if big else 4, b"\0")
+            buf += struct.pack("<HH", tag, typ) + struct.pack("<Q" if big else "<I", cnt) + field
+        buf += struct.pack("<Q" if big else "<I", next_ifd)
+        if extra:
+            buf += desc
+        f.seek(pos)
+        f.write(buf)
+        f.seek(data_off)
+        np.ascontiguousarray(page, dtype=self.dtype).tofile(f)
+        self.pos = next_ifd
+        self.z += 1
+
+
+def write_tiff(path, vol):
+    """One uncompressed strip and one IFD per page, little-endian; BigTIFF above 4 GiB."""
+    vol = np.asarray(vol)
+    if vol.ndim == 2:
+        vol = vol[None]
+    with open(path, "wb") as f:
+        pages = _TiffPages(f, vol.shape, vol.dtype)
+        for z in range(vol.shape[0]):
+            pages.write_page(vol[z])
     return path
+
+
+class VolumeWriter:
+    """The output file of the CLI written slab after slab, in Z order, while later slabs are still on their way from the
+    GPU (seq:558-571's rules: MRC float32 with header statistics, else a TIFF stack of the array's dtype).
+    `stats` (min / max / mean / std of the whole volume) is needed up front for an MRC header."""
+
+    def __init__(self, path, shape, dtype, stats=None):
+        self.mrc = is_mrc_output(path)
+        self.f = open(path, "wb")
+        self.shape = tuple(shape)
+        if self.mrc:
+            if stats is None:
+                raise ValueError("an MRC header needs the volume's statistics")
+            self.f.write(_mrc_header(self.shape, stats))
+        else:
+            self.pages = _TiffPages(self.f, self.shape, dtype)
+
+    def write_slab(self, slab):
+        if self.mrc:
+            np.ascontiguousarray(slab, dtype="<f4").tofile(self.f)
+        else:
+            for page in slab:
+                self.pages.write_page(page)
+
+    def close(self):
+        self.f.close()
 
 
 # ---------------------------------------------------------------------------- dispatch (CLI rules)
@@ -289,14 +341,16 @@ def read_slab(path, z0, z1):
     return read_tiff(path, zrange=(z0, z1))
 
 
-def write_volume(path, vol, tiff_float32=False):
+def write_volume(path, vol, tiff_float32=False, stats=None):
     """seq:558-571: MRC float32, else TIFF uint8 if max < 256 else uint16 (values truncated by astype);
-    tiff_float32=True gives par:548's float32 TIFF."""
+    tiff_float32=True gives par:548's float32 TIFF.  stats: min / max / mean / std of `vol` if already known."""
     if is_mrc_output(path):
-        write_mrc(path, vol.astype(np.float32, copy=False))
+        write_mrc(path, vol.astype(np.float32, copy=False), stats=stats)
     elif tiff_float32:
         write_tiff(path, vol.astype(np.float32, copy=False))
-    elif np.max(vol) < 256:
+    elif vol.dtype in (np.uint8, np.uint16):            # already downcast (on the GPU, operators.filter_3d_own_mean)
+        write_tiff(path, vol)
+    elif (stats["max"] if stats is not None else np.max(vol)) < 256:
         write_tiff(path, vol.astype(np.uint8))
     else:
         write_tiff(path, vol.astype(np.uint16))

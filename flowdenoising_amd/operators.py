@@ -138,38 +138,124 @@ def _as_f32(vol):
     return np.ascontiguousarray(vol, dtype=np.float32)
 
 
-def filter_3d_own_mean(vol, kernel, params, device=0):
+def filter_3d_own_mean(vol, kernel, params, device=0, stats=None, float32_semantics=False, tiff_downcast=False, timing=None,
+                       sink=None):
     """Upload, take vol.mean() (seq:420) on the GPU -- fdn_mean_dev reproduces numpy's float32 reduction bit
-    for bit, and a 2 GiB volume costs numpy 0.3 s on the host -- run the passes, download."""
-    params = integer_semantics(vol, params)
-    vol = _as_f32(vol)
+    for bit, and a 2 GiB volume costs numpy 0.3 s on the host -- run the passes, download.
+    An 8- or 16-bit integer volume travels as it is and becomes float32 on the device (fdn_convert_dev: exact).
+    stats: a dict that receives {"in": {...}, "out": {...}} (min, max, mean, std of the input and output volumes,
+    fdn_stats_dev) -- what the reference's CLI logs and mrcfile puts into the output header, taken on the GPU.
+    float32_semantics: the integer array stands for `vol.astype(np.float32)` (a TIFF stack, seq:517): plain float32
+    arithmetic, but the conversion happens on the device.
+    tiff_downcast: return what seq:566-571 writes into a TIFF -- `filtered.astype(np.uint8)` if its maximum is below
+    256, else `np.uint16` -- cast on the device (fdn_truncate_dev), so that a quarter or half of the bytes come back.
+    timing: a dict that receives wall seconds of the phases: "h2d", "compute", "d2h" (tools/cli_wall.py).
+    sink: `sink(dtype, stats_out)` returns an object with write_slab(array) / close() (io.VolumeWriter): the result is
+    then downloaded in slabs of Z slices and every slab is handed to it, in order, from a second thread -- the file
+    write of one slab overlaps the download of the next (the reference writes after its last pass, seq:558-571)."""
+    import time
+    tick = [time.perf_counter()]
+
+    def lap(name):
+        if timing is not None:
+            h.synchronize()
+            now = time.perf_counter()
+            timing[name] = timing.get(name, 0.0) + now - tick[0]
+            tick[0] = now
+
+    if not float32_semantics:
+        params = integer_semantics(vol, params)
+    vol = np.asarray(vol)
+    if vol.ndim != 3:
+        raise ValueError(f"expected a (Z, Y, X) volume, got shape {vol.shape}")
+    raw_int = vol.dtype.kind in "iu" and vol.dtype.itemsize <= 2 and vol.dtype.isnative
+    src = np.ascontiguousarray(vol) if raw_int else _as_f32(vol)
     h = handle(device)
-    d_in = h.malloc(vol.nbytes)
+    nbytes = src.size * 4
+    d_in = h.malloc(nbytes)
     try:
-        d_out = h.malloc(vol.nbytes)
+        d_out = h.malloc(nbytes)
         try:
-            out = np.empty_like(vol)
-            big = vol.nbytes >= (8 << 20)
-            pin_in = big and vol.flags["WRITEABLE"] and h.host_register(vol)      # DMA at PCIe speed instead of staged copies
+            out = np.empty(src.shape, dtype=np.float32)
+            big = src.nbytes >= (8 << 20)
+            pin_in = big and src.flags["WRITEABLE"] and h.host_register(src)      # DMA at PCIe speed instead of staged copies
             try:
-                h.h2d(d_in, vol)
+                if raw_int:      # raw integers into the (larger) output buffer, float32 from there into d_in
+                    h.h2d(d_out, src)
+                    h.convert_dev(d_out, src.dtype, d_in, src.size)
+                else:
+                    h.h2d(d_in, src)
             finally:
                 if pin_in:
-                    h.host_unregister(vol)
+                    h.host_unregister(src)
+            lap("h2d")
+            if stats is not None:
+                stats["in"] = h.stats_dev(d_in, src.size)
             # an integer volume's mean is numpy's float64 one (params.pad64); Farneback sees it as float32
-            mean = np.float32(params.pad64) if params.warp_mode == _lib.WARP_F64_PADDED else h.mean_dev(d_in, vol.size)
-            h.filter_3d_dev(d_in, d_out, vol.shape, kernel, mean, params)
+            mean = np.float32(params.pad64) if params.warp_mode == _lib.WARP_F64_PADDED else h.mean_dev(d_in, src.size)
+            h.filter_3d_dev(d_in, d_out, src.shape, kernel, mean, params)
+            if stats is not None or tiff_downcast:
+                st_out = h.stats_dev(d_out, src.size)
+                if stats is not None:
+                    stats["out"] = st_out
+            d_res = d_out
+            if tiff_downcast:
+                out = np.empty(src.shape, dtype=np.uint8 if st_out["max"] < 256 else np.uint16)
+                h.truncate_dev(d_out, out.dtype, d_in, src.size)      # the input's device copy is no longer needed
+                d_res = d_in
+            lap("compute")
             pin_out = big and h.host_register(out)
             try:
-                h.d2h(out, d_out)
+                if sink is None:
+                    h.d2h(out, d_res)
+                else:
+                    _download_into(h, out, d_res, sink(out.dtype, st_out if (stats is not None or tiff_downcast) else None))
             finally:
                 if pin_out:
                     h.host_unregister(out)
+            lap("d2h")
             return out
         finally:
             h.free(d_out)
     finally:
         h.free(d_in)
+
+
+def _download_into(h, out, d_res, writer, slab_bytes=128 << 20):
+    """Device -> `out` in slabs of whole Z slices; each slab goes to writer.write_slab from a second thread as soon as it
+    has arrived, so that writing the file overlaps the rest of the download.  Closes the writer."""
+    import queue
+    import threading
+    Z = out.shape[0]
+    per = out[0].nbytes
+    step = max(1, int(slab_bytes // max(per, 1)))
+    q = queue.Queue()
+    err = []
+
+    def drain():
+        while True:
+            item = q.get()
+            if item is None:
+                return
+            try:
+                if not err:
+                    writer.write_slab(out[item[0]:item[1]])
+            except Exception as e:      # keep draining so that the producer never blocks; re-raised below
+                err.append(e)
+
+    t = threading.Thread(target=drain, daemon=True)
+    t.start()
+    try:
+        for z0 in range(0, Z, step):
+            z1 = min(Z, z0 + step)
+            h.d2h(out[z0:z1], d_res + z0 * per)
+            q.put((z0, z1))
+    finally:
+        q.put(None)
+        t.join()
+        writer.close()
+    if err:
+        raise err[0]
 
 
 def OF_filter(vol, kernel, l, w, border_mode=_lib.BORDER_MEAN_PAD, chained=True, device=0):

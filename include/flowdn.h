@@ -196,6 +196,10 @@ int fdn_filter_axis(fdn_handle h, const float* in, float* out, int Z, int Y, int
  *      (par:285-290) ------------------------------------------------------------------ */
 /* Z pass, then Y, then X, each consuming the previous output; kernels[a] == NULL (or
  * K[a] == 0) skips axis a.  pad_value is ONE scalar for all passes (seq:420). */
+/* Allocate every device buffer fdn_filter_3d_dev will use for a volume of this shape, these tap counts and parameters,
+ * and launch nothing: a caller that knows the shape before it has the voxels (a file header, seq:508-517) runs this
+ * while it reads the file, so that the first real call does not pay for 25 GB of hipMalloc (0.4 s at configs[2]). */
+int fdn_reserve_3d(fdn_handle h, int Z, int Y, int X, const int K[3], const fdn_sweep_params* p);
 int fdn_filter_3d_dev(fdn_handle h, const float* d_in, float* d_out, int Z, int Y, int X,
                       const double* const kernels[3], const int K[3], float pad_value,
                       const fdn_sweep_params* p);
@@ -218,6 +222,19 @@ int fdn_np_chunk_sums_dev(fdn_handle h, const float* d_in, size_t count, float* 
 /* sum only (float64): the fallback for the multi-GPU mean when slabs do not start at chunk boundaries
  * (at most 1 ulp from numpy's value) */
 int fdn_sum_dev(fdn_handle h, const float* d_in, size_t count, double* sum_out);
+/* {min, max, mean, standard deviation} of a DEVICE float32 array in float64 (two passes): the header statistics
+ * mrcfile's set_data computes for the output file (seq:562-564: dmin, dmax, dmean, rms) and what seq:529-532 / 547-550
+ * log about the input and output volumes -- taken where the volume already is instead of by numpy on the host
+ * (six reductions over 2 GiB cost the reference's CLI about 2 s). */
+int fdn_stats_dev(fdn_handle h, const float* d_in, size_t count, double* out4);
+/* d_dst[i] = (float)d_src[i] for an 8- or 16-bit integer DEVICE array (depth: FDN_DEPTH_I16 / U16 / I8 / U8):
+ * seq:517's `vol.astype(np.float32)` of a TIFF stack, and the device copy of an integer MRC, without a float32 copy
+ * on the host (a 2048 x 2048 x 512 uint16 stack is 2 GiB on the wire instead of 8). */
+int fdn_convert_dev(fdn_handle h, const void* d_src, int depth, float* d_dst, size_t count);
+/* the reverse for the TIFF output of seq:566-571 (`filtered.astype(np.uint8)` if max < 256 else `np.uint16`):
+ * d_dst[i] = (uint8 / uint16) d_src[i], C's truncating cast as numpy performs it (depth FDN_DEPTH_U8 / U16);
+ * d_dst must not overlap d_src. */
+int fdn_truncate_dev(fdn_handle h, const float* d_src, int depth, void* d_dst, size_t count);
 
 /* ---- slab primitives (multi-GPU decomposition; the reviewer variant
  *      tests/flowdenoising_reviewer_solution2.py:496-508 keeps "chunk + kernel.size"

@@ -453,6 +453,58 @@ def test_wide_kernel_y_and_x_passes_spot_parity(fdn, oracle, axis, shape):
         assert np.array_equal(np.take(got, [t], axis=axis), np.take(want, [t - lo], axis=axis))
 
 
+def test_device_statistics_and_casts(fdn):
+    """The CLI's host-side numpy passes moved to the GPU: fdn_stats_dev (the statistics seq:529-532 / 547-550 log and
+    mrcfile writes into the output header), fdn_convert_dev (seq:517's astype(np.float32) of an integer stack) and
+    fdn_truncate_dev (seq:566-571's astype(np.uint8 / np.uint16) of the result, numpy's truncating, wrapping cast)."""
+    from flowdenoising_amd.operators import handle
+    rng = np.random.default_rng(5)
+    h = handle()
+    v = (rng.standard_normal(1_000_003) * 300 + 40).astype(np.float32)
+    v[17], v[900_000] = -1.75, 70000.5              # a negative voxel wraps, one above 65535 wraps too
+    d = h.malloc(v.nbytes)
+    d2 = h.malloc(v.nbytes)
+    try:
+        h.h2d(d, v)
+        st = h.stats_dev(d, v.size)
+        v64 = v.astype(np.float64)
+        assert st["min"] == v.min() and st["max"] == v.max()
+        assert abs(st["mean"] - v64.mean()) <= 1e-12 * abs(v64.mean()) + 1e-12 and abs(st["std"] - v64.std()) <= 1e-10 * v64.std()
+        for dt in (np.uint16, np.uint8):
+            h.truncate_dev(d, dt, d2, v.size)
+            got = np.empty(v.size, dtype=dt)
+            h.d2h(got, d2)
+            with np.errstate(invalid="ignore"):
+                assert np.array_equal(got, v.astype(np.int32).astype(dt))     # truncate toward zero, keep the low bits
+        for dt in (np.uint16, np.int16, np.uint8, np.int8):
+            info = np.iinfo(dt)
+            raw = rng.integers(info.min, info.max + 1, size=100_001).astype(dt)
+            h.h2d(d, raw)
+            h.convert_dev(d, dt, d2, raw.size)
+            got = np.empty(raw.size, dtype=np.float32)
+            h.d2h(got, d2)
+            assert np.array_equal(got, raw.astype(np.float32))
+    finally:
+        h.free(d)
+        h.free(d2)
+
+
+def test_operator_with_device_side_casts_equals_host_side_casts(fdn):
+    """filter_3d_own_mean on a uint16 stack with float32 semantics (a TIFF, seq:517) and the TIFF down-cast of
+    seq:566-571 on the device: the same voxels as astype(np.float32) before and astype(np.uint16) after on the host."""
+    from flowdenoising_amd.operators import _params, filter_3d_own_mean
+    vol = (np.clip(_vol((9, 40, 70), seed=23), 0, None) * 40).astype(np.uint16)
+    ks = [fdn.get_gaussian_kernel(1.0), fdn.get_gaussian_kernel(0.5), fdn.get_gaussian_kernel(0.5)]
+    stats = {}
+    got = filter_3d_own_mean(vol, ks, _params(0, 5), stats=stats, float32_semantics=True, tiff_downcast=True)
+    want = fdn.OF_filter(vol.astype(np.float32), ks, 0, 5)
+    assert got.dtype == np.uint16 and np.array_equal(got, want.astype(np.uint16))
+    assert stats["out"]["max"] == want.max() and stats["in"]["min"] == vol.min()
+    small = (vol // 300).astype(np.uint16)          # maximum below 256: the reference writes uint8 (seq:566)
+    got8 = filter_3d_own_mean(small, ks, _params(0, 5), float32_semantics=True, tiff_downcast=True)
+    assert got8.dtype == np.uint8 and np.array_equal(got8, fdn.OF_filter(small.astype(np.float32), ks, 0, 5).astype(np.uint8))
+
+
 def test_non_finite_voxels_do_not_derail_the_kernels(fdn):
     """A NaN and an Inf voxel (dead detector pixels happen): every gather / remap index is clamped, so the
     sweep completes, and the damage stays in the columns the running sums carry it down (OpenCV's box
