@@ -145,6 +145,69 @@ def numpy_par_sweep(cv2, vol, kernels, l, w):
     return vol
 
 
+def cv2_identity(cv2):
+    """Version and the build lines that decide the arithmetic (SIMD baseline / dispatch, IPP, FMA): recorded with every
+    fixture and printed with every mismatch, so that a difference can be attributed to a build, not guessed at."""
+    info = {"version": getattr(cv2, "__version__", "stand-in")}
+    try:
+        lines = cv2.getBuildInformation().splitlines()
+        keep = [ln.strip() for ln in lines if any(k in ln for k in ("CPU/HW features", "Baseline:", "Dispatched code", "requested:", "Intel IPP", "Version control", "FP16", "AVX"))]
+        info["build"] = keep[:16]
+    except Exception:
+        info["build"] = []
+    return info
+
+
+def remap_unquantised(src, flow):
+    """The OTHER reading of cv2.remap(INTER_LINEAR, BORDER_REPLICATE) on a float map: plain float32 bilinear
+    interpolation at the map position, no 1/32-pixel coordinate table.  The oracle and the HIP kernels model the classic
+    path (INTER_BITS = 5: coordinates rounded to 1/32 px, weights from the 32 x 32 table).  OpenCV 4.11+
+    is reported to ship new linear remap kernels for float maps that may not quantise; `opencv-python` is unpinned in
+    the reference (src/requirements.txt:2), so a fresh install could be either.  Diagnostic model only."""
+    H, W = flow.shape[:2]
+    mx = (flow[..., 0].astype(np.float64) + np.arange(W)[None, :]).astype(np.float32)
+    my = (flow[..., 1].astype(np.float64) + np.arange(H)[:, None]).astype(np.float32)
+    x0 = np.floor(mx)
+    y0 = np.floor(my)
+    fx = (mx - x0).astype(np.float32)
+    fy = (my - y0).astype(np.float32)
+    x0 = x0.astype(np.int64)
+    y0 = y0.astype(np.int64)
+    xa, xb = np.clip(x0, 0, W - 1), np.clip(x0 + 1, 0, W - 1)
+    ya, yb = np.clip(y0, 0, H - 1), np.clip(y0 + 1, 0, H - 1)
+    s = np.asarray(src, dtype=np.float32)
+    one = np.float32(1)
+    top = s[ya, xa] * (one - fx) + s[ya, xb] * fx
+    bot = s[yb, xa] * (one - fx) + s[yb, xb] * fx
+    return (top * (one - fy) + bot * fy).astype(np.float32)
+
+
+def classify_remap(src, flow, observed, quantised):
+    """Which remap model does `observed` (cv2's output) follow?  Returns (verdict, err_quantised, err_unquantised)."""
+    eq = float(np.abs(observed.astype(np.float64) - quantised).max())
+    eu = float(np.abs(observed.astype(np.float64) - remap_unquantised(src, flow)).max())
+    scale = max(float(np.abs(np.asarray(src, dtype=np.float64)).max()), 1e-30)
+    if eq == 0:
+        verdict = "classic 1/32-pixel table (INTER_BITS = 5): the modelled path, bit for bit"
+    elif eu <= 4e-7 * scale and eu < eq:
+        verdict = "UNQUANTISED float bilinear: this cv2 build does not use the 1/32-pixel table for float maps"
+    elif eq < eu:
+        verdict = "closer to the classic 1/32-pixel table, but not bit-equal (weights / accumulation order differ)"
+    else:
+        verdict = "closer to unquantised float bilinear than to the 1/32-pixel table"
+    return verdict, eq, eu
+
+
+def assert_warp_matches(cv2, src, flow, got, label):
+    """`got` (oracle or HIP remap) against cv2.remap; on a mismatch say WHICH model this cv2 follows, with its version."""
+    want = cv2_warp(cv2, src, flow)
+    if np.array_equal(got, want):
+        return
+    verdict, eq, eu = classify_remap(src, flow, want, np.asarray(got, dtype=np.float64))
+    raise AssertionError(f"{label}: cv2.remap differs from the modelled remap (max |diff| {eq:.3g}; against unquantised float bilinear "
+                         f"{eu:.3g}) -> {verdict}.  cv2 {cv2_identity(cv2)}")
+
+
 def _flow_err(got, want):
     return float(np.abs(got - want).max() / max(np.abs(want).max(), 1.0))
 
@@ -168,7 +231,7 @@ def test_oracle_farneback_and_remap_against_cv2(oracle, shape, l, w):
         assert _flow_err(got, want) < TOL
         if l == 0:
             assert exact
-        assert np.array_equal(oracle.warp_slice(b, want), cv2_warp(cv2, b, want))
+        assert_warp_matches(cv2, b, want, oracle.warp_slice(b, want), f"oracle remap {shape}")
     want = cv2_flow(cv2, a, b, l, w, None)                        # par:89-114: flags = 0
     assert _flow_err(oracle.calcOpticalFlowFarneback(a, b, None, 0.5, l, w, 3, 5, 1.2, 0), want) < TOL
 
@@ -196,7 +259,7 @@ def test_hip_farneback_and_remap_against_cv2(fdn, shape, l, w):
         got = fdn.get_flow(b, a, l, w, init.copy())
         _report(f"hip flow {shape} l={l} w={w}", got, want)
         assert _flow_err(got, want) < TOL
-        assert np.array_equal(fdn.warp_slice(b, want), cv2_warp(cv2, b, want))
+        assert_warp_matches(cv2, b, want, fdn.warp_slice(b, want), f"hip remap {shape}")
 
 
 @pytest.mark.gpu
@@ -212,6 +275,44 @@ def test_hip_config0_against_cv2(fdn):
 
 
 # ---- the harness itself (runs everywhere) -----------------------------------------------------------------------
+def test_remap_model_diagnostic_tells_the_two_models_apart(oracle):
+    """The day cv2 exists, a remap mismatch must be diagnosed in one run, not read as an oracle bug: a stand-in cv2
+    whose remap is the classic table model passes; one whose remap is plain float bilinear (what OpenCV >= 4.11 may do)
+    fails with a message that names the unquantised model and the cv2 version."""
+    a, b, f0 = make_pair((64, 64), 164)
+    flow = (f0 * 3).astype(np.float32)
+
+    class Classic:
+        __version__ = "stand-in classic"
+        INTER_LINEAR, BORDER_REPLICATE = 1, 1
+
+        @staticmethod
+        def remap(src, m, _, interpolation, borderMode):
+            return oracle.remap(src, m)
+
+    class Unquantised(Classic):
+        __version__ = "stand-in 4.11-like"
+
+        @staticmethod
+        def remap(src, m, _, interpolation, borderMode):
+            H, W = m.shape[:2]
+            f = np.empty_like(m)
+            f[..., 0] = m[..., 0] - np.arange(W, dtype=np.float32)[None, :]
+            f[..., 1] = m[..., 1] - np.arange(H, dtype=np.float32)[:, None]
+            return remap_unquantised(src, f)
+
+    modelled = oracle.warp_slice(b, flow)
+    assert_warp_matches(Classic, b, flow, modelled, "classic stand-in")
+    # integer-valued flows: both models agree exactly (no fractional coordinate to quantise)
+    fi = np.round(flow)
+    assert np.array_equal(oracle.warp_slice(b, fi), remap_unquantised(b, fi))
+    with pytest.raises(AssertionError, match="UNQUANTISED float bilinear.*stand-in 4.11-like"):
+        assert_warp_matches(Unquantised, b, flow, modelled, "4.11-like stand-in")
+    assert classify_remap(b, flow, modelled.astype(np.float32), modelled.astype(np.float64))[0].startswith("classic")
+    assert cv2_identity(Classic)["version"] == "stand-in classic"
+
+
+
 def test_harness_sweep_is_seq_shaped(oracle):
     """cv2_of_filter / cv2_flow / cv2_warp above are this file's own code; so that they are known to be right on
     the day cv2 appears, they are run here with a stand-in object whose two functions forward to the oracle:
@@ -344,7 +445,11 @@ def test_oracle_against_committed_cv2_fixtures(oracle, path):
         l, w = int(g["l"]), int(g["w"])
         got = oracle.get_flow(g["reference"], g["target"], l, w, g["init"].copy())
         assert _flow_err(got, g["flow"]) < TOL
-        assert np.array_equal(oracle.warp_slice(g["reference"], g["flow"]), g["warped"])
+        got_w = oracle.warp_slice(g["reference"], g["flow"])
+        if not np.array_equal(got_w, g["warped"]):
+            verdict, eq, eu = classify_remap(g["reference"], g["flow"], g["warped"], got_w.astype(np.float64))
+            raise AssertionError(f"{os.path.basename(path)} (cv2 {g['cv2_version'] if 'cv2_version' in g else '?'}): remap differs from the "
+                                 f"modelled one by {eq:.3g} (unquantised model: {eu:.3g}) -> {verdict}")
     else:
         k = oracle.get_gaussian_kernel(float(g["sigma"]))
         got = oracle.OF_filter(g["vol"], [k, k, k], int(g["l"]), int(g["w"]), nthreads=8)

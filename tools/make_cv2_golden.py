@@ -22,7 +22,16 @@ def main():
     import cv2
     import test_cv2_pin as T
     from flowdenoising_amd.synth import make_volume
-    print("cv2", cv2.__version__)
+    ident = T.cv2_identity(cv2)
+    print("cv2", ident)
+    import json
+    with open(os.path.join(T.GOLD, "cv2_identity.json"), "w") as f:      # which build produced the fixtures (version, SIMD / IPP lines)
+        json.dump(ident, f, indent=1)
+    # which remap model does this build follow?  (OpenCV >= 4.11 may not use the 1/32-pixel table for float maps)
+    from oracle import oracle as O0
+    a0, b0, f00 = T.make_pair((64, 64), 164)
+    fl = (f00 * 3).astype(np.float32)
+    print("remap model:", T.classify_remap(b0, fl, T.cv2_warp(cv2, b0, fl), O0.warp_slice(b0, fl).astype(np.float64)))
     for shape in T.PAIR_SHAPES[:2]:
         for l, w in T.PAIR_PARAMS:
             a, b, f0 = T.make_pair(shape, 100 + shape[0])
