@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--shape", default="512,1024,1024", help="Z,Y,X")
     ap.add_argument("--sigma", type=float, default=2.0)
+    ap.add_argument("--sigmas", default="", help="per-axis sigmas Z,Y,X (configs[4] is 2,2,4); overrides --sigma")
     ap.add_argument("--axes", default="zyx", help="subset of zyx (configs[1] is 'z')")
     ap.add_argument("--amplitude", type=float, default=100.0)
     ap.add_argument("--levels", type=int, default=0, help="pyramid levels (-l); configs[4] uses 3")
@@ -306,8 +307,12 @@ def main():
 
     shape = tuple(int(v) for v in a.shape.split(","))
     Z, Y, X = shape
-    kernel = _lib.gaussian_kernel(a.sigma)
-    kernels = [kernel if c in a.axes else None for c in "zyx"]
+    sig3 = [float(v) for v in a.sigmas.split(",")] if a.sigmas else [a.sigma] * 3
+    if len(sig3) != 3:
+        sys.exit("--sigmas takes three values: Z,Y,X")
+    ks3 = [_lib.gaussian_kernel(v) for v in sig3]
+    kernel = ks3[0]                  # the auxiliary lines (roofline byte model, sweep kernel, CPU sample) use the Z pass's taps
+    kernels = [ks3[i] if c in a.axes else None for i, c in enumerate("zyx")]
     naxes = sum(k is not None for k in kernels)
     params = _lib.SweepParams(a.levels, a.winsize, 3, 5, 1.2, _lib.BORDER_MEAN_PAD, 1, 1)
     if a.integer == "par":
@@ -392,7 +397,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
             "backend": (dist.get_backend() if world > 1 else "none"),
-            "config": {"workload": f"{X}x{Y}x{Z} float32, sigma={a.sigma:g} (K={kernel.size}), levels={a.levels}, winsize={a.winsize}, "
+            "config": {"workload": f"{X}x{Y}x{Z} float32, sigma={a.sigmas or format(a.sigma, 'g')} (K={','.join(str(k.size) for k in ks3)}), levels={a.levels}, winsize={a.winsize}, "
                                    f"OF along {a.axes.upper()}, mean-padded borders (BASELINE.json configs[2])",
                        "axes": a.axes, "parallelism": parallelism, "amplitude": a.amplitude,
                        "amplitude_note": "BASELINE.md's unit-range generator scaled by 100: OpenCV's absolute +1e-3 regulariser zeroes "
@@ -401,12 +406,12 @@ def main():
         }
         # whole path against the SURVEY 8(d) stage list (4832 B/voxel/axis at sigma=2): what an UNFUSED implementation
         # would have to move; above the HBM peak it measures traffic removed by fusion, not bandwidth
-        per_axis_bytes = 24 + (kernel.size - 1) * 300 + 8
-        res["whole_path"] = {"unfused_algorithmic_GBps": round(per_axis_bytes * naxes * nvox / (dt / a.steps) / 1e9 / world, 1),
-                             "ratio_to_hbm_peak_per_gpu": round(per_axis_bytes * naxes * nvox / (dt / a.steps) / 1e9 / world / HBM_PEAK_GBS, 4),
+        path_bytes = sum(24 + (k.size - 1) * 300 + 8 for k in kernels if k is not None)
+        res["whole_path"] = {"unfused_algorithmic_GBps": round(path_bytes * nvox / (dt / a.steps) / 1e9 / world, 1),
+                             "ratio_to_hbm_peak_per_gpu": round(path_bytes * nvox / (dt / a.steps) / 1e9 / world / HBM_PEAK_GBS, 4),
                              "note": "SURVEY 8(d) bytes of the unfused stage list / wall time; a ratio above 1 = traffic that fusion removed"}
         if timers:
-            run_cfg = {"shape": list(shape), "winsize": a.winsize, "levels": a.levels, "sigma": a.sigma, "axes": a.axes}
+            run_cfg = {"shape": list(shape), "winsize": a.winsize, "levels": a.levels, "sigma": a.sigma if not a.sigmas else a.sigmas, "axes": a.axes}
             res["roofline"] = roofline(timers, nvox // world, kernel.size, a.levels, run_cfg)
             res["kernel_ms_per_step"] = {k: round(v[0] / a.steps, 2) for k, v in timers.items() if v[1]}
         if phases:

@@ -3,7 +3,7 @@
 #   gpurun_out/prof_trace/**/*_kernel_stats.csv -> profiles/rNN_kernel_stats.csv
 #   gpurun_out/bench_prof.json                  -> profiles/rNN_bench.json
 #   gpurun_out/pmc_summary.txt                  -> profiles/rNN_pmc_summary.txt
-#   gpurun_out/traffic.json                     -> profiles/r02_traffic.json   (what bench.py reads)
+#   gpurun_out/traffic.json                     -> profiles/rNN_traffic.json   (bench.py picks the newest matching one)
 # usage: bash tools/profile_round.sh <commit>
 COMMIT=${1:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
