@@ -274,9 +274,10 @@ def self_launch(a):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this host driver
     env.setdefault("OMP_NUM_THREADS", "2")
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
-    for line in proc.stdout:                                 # stderr goes straight through; stdout carries the JSON line
-        sys.stdout.write(line)
-        sys.stdout.flush()
+    for line in proc.stdout:       # stderr goes straight through.  Only the JSON line is relayed on stdout: gloo (the rehearsal
+        out = sys.stdout if line.lstrip().startswith("{") else sys.stderr     # backend) prints its connection banner to stdout
+        out.write(line)
+        out.flush()
     return proc.wait()
 
 

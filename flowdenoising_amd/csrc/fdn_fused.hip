@@ -489,16 +489,16 @@ static void launch_variant(const float* Rstack, const float* stack, const float*
     }
 }
 
-// Workgroups per CU for a grid of `blocks` workgroups (winsize 4-5 builds).  All workgroups of a launch take
-// about the same time, so what counts is the number of rounds: large grids run fastest at 4 per CU [17.2 ms for
-// 10240 workgroups against 18.1 at 3 and 18.0 at 5], but a grid that fits one round at 5 and not at 4
-// -- 1280 workgroups: the 64-slice Z slab of an 8-GPU run -- gains 16 % there [2.69 against 3.21 ms].
-// Measured no better: 5 per CU for 2560 workgroups (2 rounds instead of 3), 3 per CU anywhere.
+// Workgroups per CU for a grid of `blocks` workgroups (winsize 4-5 builds): large grids run fastest at 4 per CU (round 3,
+// 5 120 / 2 560 workgroups: 7.78 / 4.04 ms at 4; 8.09 / 4.24 at 3; 8.70 / 4.57 at 5).  A grid of at most 5 workgroups per
+// CU -- 1 280: the 64-slice Z slab of an 8-GPU run -- is not short of slots but of speed per workgroup, and the build
+// with the largest LDS window is the fastest there: 2.18 ms at 3 per CU, 2.22 at 4, 2.28 at 5 (round 2, before the edge
+// bands lost their ds_bpermute path, 5 per CU had won that grid: 2.69 against 3.21).
 static int choose_occupancy(long blocks, const Tuning& tn)
 {
     if (tn.fused_occ >= 3 && tn.fused_occ <= 5) return tn.fused_occ;
     if (tn.fused_occ == 8) return 4;
-    return blocks > (long)tn.cus * 4 && blocks <= (long)tn.cus * 5 ? 5 : 4;
+    return blocks <= (long)tn.cus * 5 ? 3 : 4;
 }
 
 // acc == nullptr: Farneback only (a coarser pyramid level), flow_out is required then.

@@ -46,6 +46,25 @@ static __host__ __device__ constexpr int window_block(int n)
     return p < 2 ? 2 : p;
 }
 
+#ifndef FDN_ITER_DPP_BLOCKS
+#define FDN_ITER_DPP_BLOCKS 1
+#endif
+// whole-wave lane shifts of an f64 (DPP wave_shr:1 / wave_shl:1 on the two halves; 0 comes in at the ends), as in fdn_fused.hip
+static __device__ __forceinline__ double lane_shr1(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+static __device__ __forceinline__ double lane_shl1(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 static __device__ __forceinline__ void lds_barrier_iter()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -230,15 +249,33 @@ __global__ __launch_bounds__(ACC ? 192 : 128) void k_farneback_iter(const float*
             {
                 double* row0 = xch;
                 double* row1 = xch + XR;
+                // the single columns go to LDS only when the window's tail (rem) reads them; the blocks of p <= 3
+                // consecutive columns are summed by lane shifts (same terms, same order; a shift brings 0 in at the
+                // wave's ends where the LDS row holds the neighbouring channel: halo lanes only, either way) --
+                // one write -> read round trip per row instead of two (FDN_ITER_DPP_BLOCKS = 0: both levels through LDS)
+                const bool dpp_blocks = FDN_ITER_DPP_BLOCKS && MHT != 0 && WP <= 3;
+                if (!dpp_blocks || WREM > 0) {
 #pragma unroll
-                for (int c = 0; c < 5; c++) row0[c * 64 + lane + MH] = vs[c];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                    for (int c = 0; c < 5; c++) row0[c * 64 + lane + MH] = vs[c];
+                }
+                if (!dpp_blocks) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
-                    const double* r = row0 + c * 64 + lane + MH;
-                    double s = WE == 0 ? vs[c] : r[-WE];
-                    for (int j = 1; j < WP; j++) s += j == WE ? vs[c] : r[j - WE];
+                    double s;
+                    if (dpp_blocks) {       // B[L] = v[L-e] + ... + v[L-e+p-1], left to right
+                        const double l1 = lane_shr1(vs[c]), r1 = lane_shl1(vs[c]);
+                        if (WP == 2) s = WE == 1 ? l1 + vs[c] : vs[c] + r1;
+                        else if (WE == 0) s = (vs[c] + r1) + lane_shl1(r1);
+                        else if (WE == 1) s = (l1 + vs[c]) + r1;
+                        else s = (lane_shr1(l1) + l1) + vs[c];
+                    } else {
+                        const double* r = row0 + c * 64 + lane + MH;
+                        s = WE == 0 ? vs[c] : r[-WE];
+                        for (int j = 1; j < WP; j++) s += j == WE ? vs[c] : r[j - WE];
+                    }
                     blk[c] = s;
                     row1[c * 64 + lane + MH] = s;
                 }

@@ -336,7 +336,7 @@ def test_strict_order_refuses_rows_it_cannot_hold(fdn):
         h.set_option("strict_order", 0)
 
 
-@pytest.mark.parametrize("env", [{}, {"FDN_FUSED_OCC": "3"}, {"FDN_FUSED_OCC": "5"}, {"FDN_FUSED_OCC": "8"}, {"FDN_FORCE_STAGED": "1"}, {"FDN_PATH": "2"}])
+@pytest.mark.parametrize("env", [{}, {"FDN_FUSED_OCC": "3"}, {"FDN_FUSED_OCC": "4"}, {"FDN_FUSED_OCC": "5"}, {"FDN_FUSED_OCC": "8"}, {"FDN_FORCE_STAGED": "1"}, {"FDN_PATH": "2"}])
 def test_kernel_variants_agree_bit_for_bit(fdn, oracle, tmp_path, env):
     """Every implementation of the chain step (the fused stage-pipelined kernel in its builds for 3, 4
     and 5 workgroups per CU -- different LDS windows and unrolls --, its two-bands-per-workgroup build, the staged per-stage
