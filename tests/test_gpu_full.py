@@ -453,6 +453,50 @@ def test_wide_kernel_y_and_x_passes_spot_parity(fdn, oracle, axis, shape):
         assert np.array_equal(np.take(got, [t], axis=axis), np.take(want, [t - lo], axis=axis))
 
 
+def test_refused_host_registration_does_not_poison_the_next_call(fdn, oracle):
+    """hipHostRegister refuses some ranges (here: one that is not mapped at all); fdn_host_register then reports an error,
+    Handle.host_register returns False and the callers fall back to pageable copies.  The runtime's sticky last-error of
+    that refusal must not surface in the next kernel-launch check (advisor finding, round 2): a filter run right after it
+    succeeds and is right."""
+    import ctypes
+    from flowdenoising_amd.operators import handle
+    h = handle()
+    vol = _vol((7, 40, 70), seed=31)
+    ks = [fdn.get_gaussian_kernel(0.5), fdn.get_gaussian_kernel(1.0), None]
+    want = oracle.OF_filter(vol, ks, 0, 5)
+    rc = h._lib.fdn_host_register(h._h, ctypes.c_void_p(1 << 20), ctypes.c_size_t(1 << 20))      # an unmapped range
+    assert rc != 0 and b"hipHostRegister" in h._lib.fdn_last_error()
+    assert h._lib.fdn_host_unregister(h._h, ctypes.c_void_p(1 << 20)) != 0                          # never registered
+    assert np.array_equal(fdn.OF_filter(vol, ks, 0, 5), want)
+
+
+def test_reserve_allocates_what_the_filter_uses(fdn):
+    """fdn_reserve_3d (the CLI runs it while it reads the file): after it, the real call allocates nothing more."""
+    from flowdenoising_amd import _lib
+    h = _lib.Handle(0)
+    try:
+        shape = (20, 96, 160)
+        ks = [fdn.get_gaussian_kernel(1.0), fdn.get_gaussian_kernel(1.0), fdn.get_gaussian_kernel(0.5)]
+        for l, w in ((0, 5), (2, 5), (1, 15)):
+            params = _lib.SweepParams(l, w, 3, 5, 1.2, _lib.BORDER_MEAN_PAD, 1, 1)
+            h.reserve_3d(shape, [k.size for k in ks], params)
+            held = h.workspace_bytes()
+            assert held > 0
+            vol = _vol(shape, seed=5)
+            n = vol.nbytes
+            d_in, d_out = h.malloc(n), h.malloc(n)
+            try:
+                h.h2d(d_in, vol)
+                h.filter_3d_dev(d_in, d_out, shape, ks, vol.mean(), params)
+                h.synchronize()
+                assert h.workspace_bytes() == held, (l, w, held, h.workspace_bytes())
+            finally:
+                h.free(d_in)
+                h.free(d_out)
+    finally:
+        h.close()
+
+
 def test_device_statistics_and_casts(fdn):
     """The CLI's host-side numpy passes moved to the GPU: fdn_stats_dev (the statistics seq:529-532 / 547-550 log and
     mrcfile writes into the output header), fdn_convert_dev (seq:517's astype(np.float32) of an integer stack) and
