@@ -23,6 +23,28 @@ static __device__ __forceinline__ int reflect101(int p, int len)
 }
 
 // ---------------------------------------------------------------------------------
+// Order in which a launch walks its pairs.  Slice s of the stack is the TARGET of pair s and the NEIGHBOUR of pair
+// s - d: its polynomial expansion (20 B/px) is read by both.  Walking the pairs in chains t, t + |d|, t + 2 |d|, ...
+// puts those two pairs next to each other in the workgroup list -- same XCD, started together, marching down the rows
+// in step -- so that the second reader finds the expansion in that XCD's L2 instead of fetching it from HBM again.
+// Speed (energy) only: position i of the walk -> pair index.  FDN_PAIR_CHAINS = 0: pairs in index order.
+// ---------------------------------------------------------------------------------
+#ifndef FDN_PAIR_CHAINS
+#define FDN_PAIR_CHAINS 1
+#endif
+static __device__ __forceinline__ int pair_walk(int i, int npairs, int d)
+{
+    const int ad = d < 0 ? -d : d;
+    if (!FDN_PAIR_CHAINS || ad < 1 || ad >= npairs) return i;
+    const int L = npairs / ad, rem = npairs - L * ad;      // chains c < rem have L + 1 members, the others L
+    const int big = rem * (L + 1);
+    int c, k;
+    if (i < big) { c = i / (L + 1); k = i - c * (L + 1); }
+    else { const int j = i - big; c = rem + j / L; k = j - (c - rem) * L; }
+    return c + k * ad;
+}
+
+// ---------------------------------------------------------------------------------
 // FarnebackUpdateMatrices' 5-pixel border damping.
 //   border_factor: border[x]-factor product for one coordinate, ((x<5 ? b[x] : 1) * (x>=W-5 ? b[W-1-x] : 1))
 // ---------------------------------------------------------------------------------

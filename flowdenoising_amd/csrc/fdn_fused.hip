@@ -134,8 +134,9 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
     const long nband_total = (long)nbands * pb.npairs;
     const bool live = gw < nband_total;          // NB = 2 and an odd number of bands: the last half repeats a band, stores off
     if (!live) gw = nband_total - 1;
-    const int b = (int)(gw / nbands);
-    const int band = (int)(gw - (long)b * nbands);
+    const int bw = (int)(gw / nbands);              // position in the walk over the pairs (pair_walk: chains of stride |d|)
+    const int band = (int)(gw - (long)bw * nbands);
+    const int b = pair_walk(bw, pb.npairs, pb.d);
     const int xb = band * BW - HALO;            // column of lane 0
     const int x = xb + lane;
     const int xc = clampi(x, 0, W - 1);

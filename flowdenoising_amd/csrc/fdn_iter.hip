@@ -100,8 +100,9 @@ __global__ __launch_bounds__(ACC ? 192 : 128) void k_farneback_iter(const float*
     const long nwg = gridDim.x, q8 = nwg >> 3, rem8 = nwg & 7;
     const long xcd = blockIdx.x & 7;
     const long gw = xcd * q8 + (xcd < rem8 ? xcd : rem8) + (blockIdx.x >> 3);
-    const int b = (int)(gw / nbands);
-    const int band = (int)(gw - (long)b * nbands);
+    const int bw = (int)(gw / nbands);              // position in the walk over the pairs (pair_walk: chains of stride |d|)
+    const int band = (int)(gw - (long)bw * nbands);
+    const int b = pair_walk(bw, pb.npairs, pb.d);
     const int xb = band * BW - MH;
     const int x = xb + lane;
     const int xc = clampi(x, 0, W - 1);       // lanes outside the image replicate the border column (BORDER_REPLICATE of vsum)
