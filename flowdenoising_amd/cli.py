@@ -83,13 +83,15 @@ def _feedback(state):
         time.sleep(1)
 
 
-def _run_single(args, vol, kernels, l, w, device, stats, as_float32, timing=None):
+def _run_single(args, vol, kernels, l, w, device, stats, as_float32, timing=None, wait_for=None):
     from . import _lib
     from .operators import _params, filter_3d_own_mean
     border = _lib.BORDER_WRAP if args.compat == "par" else _lib.BORDER_MEAN_PAD
     params = _params(l, w, use_of=not args.no_OF, border_mode=border, chained=not args.recompute_flow)
     if args.chunk_slices:
         from .streaming import filter_streamed
+        if wait_for is not None:
+            wait_for()
         if as_float32:
             vol = vol.astype(np.float32)            # seq:517
         return filter_streamed(vol, kernels, l, w, None if args.chunk_slices < 0 else args.chunk_slices,
@@ -104,7 +106,7 @@ def _run_single(args, vol, kernels, l, w, device, stats, as_float32, timing=None
         stats["streamed"] = True
         return fio.VolumeWriter(args.output, shape, np.float32 if (fio.is_mrc_output(args.output) or tiff32) else dtype, st_out)
     return filter_3d_own_mean(vol, kernels, params, device, stats=stats, float32_semantics=as_float32, tiff_downcast=downcast,
-                              timing=timing, sink=sink)
+                              timing=timing, sink=sink, wait_for=wait_for)
 
 
 def _reserve(args, shape, dtype, Ks, l, w):
@@ -222,7 +224,7 @@ def main(argv=None):
         vol = None
     else:
         prep = None
-        if not args.chunk_slices and not args.memory_map:
+        if not args.chunk_slices:
             try:
                 hshape, hdtype = fio.volume_info(args.input)        # header / page directory only
                 Ks = [2 * int(4.0 * s + 0.5) + 1 for s in sigma[:3]]  # seq:30-41: taps of get_gaussian_kernel(sigma)
@@ -230,9 +232,9 @@ def main(argv=None):
                 prep.start()
             except Exception:
                 prep = None
-        vol = fio.read_volume(args.input, mmap=args.memory_map)
-        if prep is not None:
-            prep.join()
+        # an MRC is memory-mapped, never copied: its pages go from the page cache to the GPU (the reference reads it into a
+        # fresh array, seq:513; -m asks for the map explicitly, seq:510-512); the buffers are being reserved meanwhile
+        vol = fio.read_volume(args.input, mmap=args.memory_map or (prep is not None and fio.is_mrc_input(args.input)))
         # seq:517, par:475: a TIFF is float32 from here on; an MRC keeps its dtype (seq:513).  An 8- or 16-bit TIFF stack
         # stays as read and is converted on the GPU (the same values, a quarter or half of the bytes on the host and the wire)
         as_float32 = not fio.is_mrc_input(args.input)
@@ -258,7 +260,8 @@ def main(argv=None):
     if sharded:
         filtered = _run_sharded(args, shape, kernels, l, w)
     else:
-        filtered = _run_single(args, vol, kernels, l, w, args.device, stats, as_float32, timing=wall)
+        filtered = _run_single(args, vol, kernels, l, w, args.device, stats, as_float32, timing=wall,
+                               wait_for=prep.join if prep is not None else None)
     wall["filter"] = time.perf_counter() - t0
     logging.info(f"Volume filtered in {wall['filter']} seconds")
     if rank != 0:

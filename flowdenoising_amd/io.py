@@ -205,7 +205,11 @@ def read_tiff(path, zrange=None, shape_only=False):
                 out[i] = src
             else:
                 f.seek(src)
-                out[i] = np.fromfile(f, dtype=dt, count=H * W).reshape(H, W)
+                if dt.isnative:          # straight into its place (np.fromfile would allocate and copy every page)
+                    if f.readinto(memoryview(out[i]).cast("B")) != H * W * dt.itemsize:
+                        raise ValueError(f"{path}: page {i} is truncated")
+                else:
+                    out[i] = np.fromfile(f, dtype=dt, count=H * W).reshape(H, W)
         return out
 
 

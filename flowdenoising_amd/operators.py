@@ -139,7 +139,7 @@ def _as_f32(vol):
 
 
 def filter_3d_own_mean(vol, kernel, params, device=0, stats=None, float32_semantics=False, tiff_downcast=False, timing=None,
-                       sink=None):
+                       sink=None, wait_for=None):
     """Upload, take vol.mean() (seq:420) on the GPU -- fdn_mean_dev reproduces numpy's float32 reduction bit
     for bit, and a 2 GiB volume costs numpy 0.3 s on the host -- run the passes, download.
     An 8- or 16-bit integer volume travels as it is and becomes float32 on the device (fdn_convert_dev: exact).
@@ -152,7 +152,10 @@ def filter_3d_own_mean(vol, kernel, params, device=0, stats=None, float32_semant
     timing: a dict that receives wall seconds of the phases: "h2d", "compute", "d2h" (tools/cli_wall.py).
     sink: `sink(dtype, stats_out)` returns an object with write_slab(array) / close() (io.VolumeWriter): the result is
     then downloaded in slabs of Z slices and every slab is handed to it, in order, from a second thread -- the file
-    write of one slab overlaps the download of the next (the reference writes after its last pass, seq:558-571)."""
+    write of one slab overlaps the download of the next (the reference writes after its last pass, seq:558-571).
+    wait_for: called after the upload and before anything is launched on the process-wide handle -- the CLI passes the
+    join of the thread in which that handle reserves its buffers (fdn_reserve_3d); the upload itself then runs on a
+    handle of its own, concurrently with it."""
     import time
     tick = [time.perf_counter()]
 
@@ -171,23 +174,28 @@ def filter_3d_own_mean(vol, kernel, params, device=0, stats=None, float32_semant
     raw_int = vol.dtype.kind in "iu" and vol.dtype.itemsize <= 2 and vol.dtype.isnative
     src = np.ascontiguousarray(vol) if raw_int else _as_f32(vol)
     h = handle(device)
+    hu = _lib.Handle(device) if wait_for is not None else h       # the upload's own handle and stream while `h` is being prepared
     nbytes = src.size * 4
-    d_in = h.malloc(nbytes)
+    d_in = hu.malloc(nbytes)
     try:
-        d_out = h.malloc(nbytes)
+        d_out = hu.malloc(nbytes)
         try:
             out = np.empty(src.shape, dtype=np.float32)
             big = src.nbytes >= (8 << 20)
-            pin_in = big and src.flags["WRITEABLE"] and h.host_register(src)      # DMA at PCIe speed instead of staged copies
+            # DMA at PCIe speed instead of staged copies.  A read-only memory map of the input file (the CLI's MRC path) is
+            # page-locked where the runtime allows it: the upload then reads the page cache directly -- no host copy at all
+            pin_in = big and hu.host_register(src)
             try:
-                if raw_int:      # raw integers into the (larger) output buffer, float32 from there into d_in
-                    h.h2d(d_out, src)
-                    h.convert_dev(d_out, src.dtype, d_in, src.size)
-                else:
-                    h.h2d(d_in, src)
+                hu.h2d(d_out if raw_int else d_in, src)      # raw integers into the (larger) output buffer first
             finally:
                 if pin_in:
-                    h.host_unregister(src)
+                    hu.host_unregister(src)
+            if wait_for is not None:
+                hu.synchronize()
+                hu.close()
+                wait_for()
+            if raw_int:
+                h.convert_dev(d_out, src.dtype, d_in, src.size)      # float32 from there into d_in
             lap("h2d")
             if stats is not None:
                 stats["in"] = h.stats_dev(d_in, src.size)
