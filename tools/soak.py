@@ -19,7 +19,7 @@ print("ok", sys.argv[1:], flush=True)
 '''
 outs = []
 for l in (0, 3):
-    for occ in ("", "3", "4", "5"):           # "": the launcher's own choice (two bands per workgroup on large grids)
+    for occ in ("", "3", "4", "5", "8"):      # "": the launcher's own choice; 8: two bands per workgroup
         fn = f"/tmp/soak_{l}_{occ or 'auto'}.npy"
         env = dict(os.environ, FDN_FUSED_OCC=occ) if occ else {k: v for k, v in os.environ.items() if k != "FDN_FUSED_OCC"}
         subprocess.run([sys.executable, "-c", code, str(l), fn, "5"], env=env, check=True)
