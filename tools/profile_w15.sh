@@ -12,4 +12,7 @@ done
 python3 tools/pmc_summary.py "gpurun_out/w15_pmc*/**/*_counter_collection.csv" "k_farneback_iter<7, 1, true>" > gpurun_out/w15_pmc_summary.txt
 python3 tools/pmc_summary.py "gpurun_out/w15_pmc*/**/*_counter_collection.csv" "k_farneback_iter<7, 1, false>" >> gpurun_out/w15_pmc_summary.txt
 cat gpurun_out/w15_pmc_summary.txt
-python3 tools/make_traffic_json.py "k_farneback_iter<7, 1, true>" gpurun_out/w15_traffic.json ${1:-unknown} "gpurun_out/w15_pmc*/**/*_counter_collection.csv" 3 15
+# what bench.py reads: the mean over the launches of every level and kind (its roofline line averages the same way) ...
+python3 tools/make_traffic_json.py "k_farneback_iter<7" gpurun_out/w15_traffic.json ${1:-unknown} "gpurun_out/w15_pmc*/**/*_counter_collection.csv" 3 15
+# ... and the level-0 warping launch on its own (512 x 1024 x 1024 pixels per launch), for DESIGN.md
+python3 tools/make_traffic_json.py "k_farneback_iter<7, 1, true>" gpurun_out/w15_traffic_level0_warp.json ${1:-unknown} "gpurun_out/w15_pmc*/**/*_counter_collection.csv" 0 15
