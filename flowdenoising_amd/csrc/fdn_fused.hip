@@ -16,13 +16,14 @@
 //                                  image (1/32-px quantised bilinear), accumulate
 //   One s_barrier per row step: everything a wave reads in step t was written in an earlier step,
 //   everything it writes goes to LDS slots nobody reads in step t.
-//   LDS per workgroup (40.7 KB -> 4 workgroups = 16 waves per CU):
+//   LDS per workgroup (40.2 KB -> 4 workgroups = 16 waves per CU):
 //     hand-over  [3][2 slots][5 ch][64 lanes]         row r of M_k sits in slot r & 1 for one step; the
 //                consumer takes it over into a six-row delay line in VGPRs (its own column of rows
 //                y-3 .. y+2 is all the running sum needs), so the matrices never reach HBM and cost
 //                7.7 KB of LDS instead of 3 x 7 rows
 //     R1 window  [rows t-2(MH+1)-D .. t+D+1][5 (64+2DX)]  (dynamic LDS, D = 7 rows, DX = 5 columns; a row holds
-//                channel pairs (0,1), (2,3) interleaved and channel 4, the RImage layout of fdn_device.h)
+//                its pixels as 16-byte quads (c0, c1, c2, c3) + a quarter-size array of c4: four aligned
+//                ds_read_b128 fetch the 2 x 2 footprint of four channels)
 //                neighbour expansion: every stage gathers its bilinear taps here.  The flows of noisy
 //                volumes span several pixels, so lanes of one wave read different ROWS: from global
 //                memory that is one cache line per lane and instruction (27 % of the kernel's time
@@ -32,10 +33,13 @@
 //   Splitting the stages over waves keeps each wave's register state small (one running sum set and
 //   one delay line: 100 VGPRs), where a single wave running all stages was latency-bound.
 //   Each iteration loses MH columns of validity either side: a band yields 64 - 6 MH = 52 output
-//   columns for winsize 5; windows that reach outside the image read the lane of the clamped
-//   column, which is BORDER_REPLICATE of the running sums.
-//   Measured (MI355X, 512 targets of 1024 x 1024): 17.1 ms per launch, VALU issue 86 % busy
-//   (DESIGN.md 3.2 has the history and the variants that lost).
+//   columns for winsize 5.  BORDER_REPLICATE of the box filter: a lane outside the image takes its
+//   matrix rows over from the hand-over slot of the lane that owns the border column, so the ordinary
+//   lane shifts deliver the border column's running sums to the windows that reach outside.  After the
+//   lane shifts only the lanes whose result is used stay active (EXEC mask).
+//   Measured (MI355X, 512 targets of 1024 x 1024): 14.4 ms per launch, VALU issue 96 % busy at the
+//   2.05 GHz the socket's 1400 W power cap leaves it (DESIGN.md 3.2 has the history and the variants
+//   that lost).
 #include "fdn_internal.h"
 #include "fdn_device.h"
 #include <stdlib.h>

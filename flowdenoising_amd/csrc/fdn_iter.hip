@@ -15,9 +15,9 @@
 //   wave 0 (producer)  row t         : M row from flow_in, R0 and the bilinear gather of R1 -> LDS ring slot t % RS
 //   wave 1 (consumer)  row t - MH - 1: OpenCV's vertical running sum vsum += f32(M[y+MH] - M[y-MH-1]) (carried in
 //                                      registers from row 0: the f32-fed recurrence is what makes results bit-faithful,
-//                                      DESIGN.md 3.2), horizontal window across lanes in two levels of blocks
-//                                      through LDS rows,
-//                                      2 x 2 solve, store
+//                                      DESIGN.md 3.2), horizontal window across lanes in two levels of blocks: the
+//                                      first (<= 3 consecutive columns) by DPP lane shifts, the second through an
+//                                      LDS row; halo lanes idle from there (EXEC mask); 2 x 2 solve, store
 //   wave 2 (warper)    row t - MH - 2: last iteration of level 0 only: the 1/32-px remap of the neighbour at p + flow
 //                                      and acc = f32(f64(acc) + f64(v) w) (seq:106-107); the flow comes from the
 //                                      consumer through two LDS slots
