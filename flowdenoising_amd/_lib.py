@@ -49,9 +49,24 @@ EXPORTS = [
     "fdn_memset_f32", "fdn_gaussian_kernel", "fdn_farneback", "fdn_farneback_strided", "fdn_farneback_dev",
     "fdn_warp", "fdn_warp_strided", "fdn_warp_dev", "fdn_farneback_typed", "fdn_warp_typed",
     "fdn_filter_axis_dev", "fdn_filter_axis", "fdn_filter_3d_dev", "fdn_filter_3d",
-    "fdn_mean_host", "fdn_mean_dev", "fdn_np_chunk_sums_dev", "fdn_sum_dev", "fdn_stats_dev", "fdn_convert_dev", "fdn_truncate_dev", "fdn_reserve_3d", "fdn_sweep_stack_dev", "fdn_permute_dev",
+    "fdn_mean_host", "fdn_mean_dev", "fdn_np_chunk_sums_dev", "fdn_sum_dev", "fdn_stats_dev", "fdn_convert_dev", "fdn_truncate_dev", "fdn_reserve_3d", "fdn_filter_3d_sharded", "fdn_sweep_stack_dev", "fdn_permute_dev",
     "fdn_enable_timers", "fdn_get_timers", "fdn_add_timer", "fdn_version",
 ]
+
+class FdnMsg(ctypes.Structure):
+    """fdn_msg (include/flowdn.h)."""
+    _fields_ = [("d_buf", ctypes.c_void_p), ("bytes", ctypes.c_size_t), ("peer", ctypes.c_int), ("is_send", ctypes.c_int)]
+
+
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(FdnMsg), ctypes.c_void_p)
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+
+
+class FdnComm(ctypes.Structure):
+    """fdn_comm (include/flowdn.h)."""
+    _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("world", ctypes.c_int),
+                ("exchange", EXCHANGE_FN), ("allgather_host", ALLGATHER_FN)]
+
 
 _lib = None
 
@@ -373,6 +388,38 @@ class Handle:
         Z, Y, X = shape
         arr = (ctypes.c_int * 3)(*[int(k) for k in Ks])
         check(self._lib.fdn_reserve_3d(self._h, ctypes.c_int(Z), ctypes.c_int(Y), ctypes.c_int(X), arr, ctypes.byref(params)))
+
+    def filter_3d_sharded(self, d_slab_in, d_slab_out, shape, kernels, params, comm):
+        """fdn_filter_3d_sharded: this rank's Z-slab in, filtered Z-slab out, the transport behind `comm`:
+        an object with .rank, .world, .exchange(msgs, stream) -- msgs = [(device pointer, nbytes, peer, is_send)] --
+        and .allgather_host(send: bytes) -> bytes of all ranks in rank order (distributed.TorchComm is one)."""
+        Z, Y, X = shape
+        ptrs, Ks, keep = self._kernels(kernels)
+        errors = []
+
+        def _exchange(ctx, n, msgs, stream):
+            try:
+                comm.exchange([(msgs[i].d_buf, msgs[i].bytes, msgs[i].peer, bool(msgs[i].is_send)) for i in range(n)], stream)
+                return 0
+            except Exception as e:          # no exception may cross the C boundary
+                errors.append(e)
+                return -1
+
+        def _allgather(ctx, send, recv, nbytes):
+            try:
+                out = comm.allgather_host(ctypes.string_at(send, nbytes))
+                ctypes.memmove(recv, out, len(out))
+                return 0
+            except Exception as e:
+                errors.append(e)
+                return -1
+
+        c = FdnComm(None, int(comm.rank), int(comm.world), EXCHANGE_FN(_exchange), ALLGATHER_FN(_allgather))
+        rc = self._lib.fdn_filter_3d_sharded(self._h, ctypes.c_void_p(d_slab_in), ctypes.c_void_p(d_slab_out), ctypes.c_int(Z),
+                                             ctypes.c_int(Y), ctypes.c_int(X), ptrs, Ks, ctypes.byref(params), ctypes.byref(c))
+        if errors:
+            raise errors[0]
+        check(rc)
 
     def filter_axis_dev(self, d_in, d_out, shape, axis, kernel, pad_value, params):
         Z, Y, X = shape

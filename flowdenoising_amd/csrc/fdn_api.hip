@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <array>
 #include <string>
 #include <vector>
 
@@ -157,6 +158,7 @@ struct fdn_ctx {
     void* pinned = nullptr;          // host staging of the pair-level entry points (hipHostMalloc)
     size_t pinned_cap = 0;
     DevBuf Rpyr, flow_pyr, pyr_tmp, area_tab;   // pyramid levels >= 1
+    DevBuf sh_send, sh_recv, sh_stack, sh_out[2], sh_tmp;   // fdn_filter_3d_sharded: staging, stack and pass outputs
     struct AreaKey { int sh, sw, dh, dw; } area_key = {0, 0, 0, 0};
     struct AreaPtrs { const int *x_si, *x_start, *y_si, *y_start; const float *x_alpha, *y_alpha; } area = {};
     // timers: event pairs are recorded asynchronously and resolved in fdn_get_timers
@@ -261,7 +263,8 @@ static int gather_host_depth(float* dst, const void* src, int depth, ptrdiff_t r
 static size_t owned_bytes(const fdn_ctx* h)
 {
     const DevBuf* bufs[] = {&h->R, &h->M0, &h->M1, &h->flow, &h->stack, &h->sweep_out, &h->vol_a, &h->vol_b, &h->partials, &h->pair,
-                            &h->vol_in, &h->vol_out, &h->Rpyr, &h->flow_pyr, &h->pyr_tmp, &h->area_tab};
+                            &h->vol_in, &h->vol_out, &h->Rpyr, &h->flow_pyr, &h->pyr_tmp, &h->area_tab,
+                            &h->sh_send, &h->sh_recv, &h->sh_stack, &h->sh_out[0], &h->sh_out[1], &h->sh_tmp};
     size_t n = 0;
     for (const DevBuf* b : bufs) n += b->cap;
     return n;
@@ -270,7 +273,8 @@ static size_t owned_bytes(const fdn_ctx* h)
 static void free_all(fdn_ctx* h)
 {
     DevBuf* bufs[] = {&h->R, &h->M0, &h->M1, &h->flow, &h->stack, &h->sweep_out, &h->vol_a, &h->vol_b, &h->partials, &h->pair,
-                      &h->vol_in, &h->vol_out, &h->Rpyr, &h->flow_pyr, &h->pyr_tmp, &h->area_tab};
+                      &h->vol_in, &h->vol_out, &h->Rpyr, &h->flow_pyr, &h->pyr_tmp, &h->area_tab,
+                      &h->sh_send, &h->sh_recv, &h->sh_stack, &h->sh_out[0], &h->sh_out[1], &h->sh_tmp};
     for (DevBuf* b : bufs) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     h->area_key = {0, 0, 0, 0};
 }
@@ -943,6 +947,259 @@ template <typename T> static T np_pairwise_sum(const T* a, size_t n)
 }
 static float np_pairwise_sum_f32(const float* a, size_t n) { return np_pairwise_sum<float>(a, n); }
 
+
+// =====================================================================================================================
+// The sharded filter below the ABI (include/flowdn.h, fdn_filter_3d_sharded): the schedule of
+// flowdenoising_amd/distributed.py (SlabPlan / SlabEngine) in C++, the transport behind two callbacks.
+// =====================================================================================================================
+namespace {
+
+struct Range { int lo, hi; };
+struct Block { int p0; Range rng[3]; };            // stack position of its first B-slice + global index ranges
+static const int ORIENT[3][3] = {{0, 1, 2}, {1, 0, 2}, {2, 0, 1}};   // stack dims (slices, H, W) of a pass as global axes
+
+struct ShardPlan {
+    int N[3], world, rank;
+    Range part(int axis, int r) const
+    {
+        const int base = N[axis] / world, rem = N[axis] % world;
+        const int s = r * base + std::min(r, rem);
+        return {s, s + base + (r < rem ? 1 : 0)};
+    }
+    // rank j's stack along `axis` holds positions p = 0 .. len_j + 2r - 1 = global slices s_j - r + p: maximal runs
+    // (p0, g0, count) of consecutive positions with consecutive global slices inside the volume (wrap: modulo)
+    void stack_runs(int axis, int j, int r, bool wrap, std::vector<std::array<int, 3>>& runs) const
+    {
+        runs.clear();
+        const int n = N[axis];
+        const Range pj = part(axis, j);
+        for (int p = 0; p < pj.hi - pj.lo + 2 * r; p++) {
+            int g = pj.lo - r + p;
+            if (wrap) g = ((g % n) + n) % n;
+            else if (g < 0 || g >= n) continue;
+            if (!runs.empty() && runs.back()[0] + runs.back()[2] == p && runs.back()[1] + runs.back()[2] == g) runs.back()[2]++;
+            else runs.push_back({p, g, 1});
+        }
+    }
+    // what rank i (partition along A) sends rank j for the pass along B
+    void blocks(int A, int B, int r, bool wrap, int i, int j, std::vector<Block>& out) const
+    {
+        out.clear();
+        const Range pi = part(A, i);
+        std::vector<std::array<int, 3>> runs;
+        stack_runs(B, j, r, wrap, runs);
+        for (auto& run : runs) {
+            Block b;
+            for (int ax = 0; ax < 3; ax++) b.rng[ax] = {0, N[ax]};
+            if (A == B) {
+                const int lo = std::max(run[1], pi.lo), hi = std::min(run[1] + run[2], pi.hi);
+                if (lo >= hi) continue;
+                b.rng[B] = {lo, hi};
+                b.p0 = run[0] + lo - run[1];
+            } else {
+                b.rng[B] = {run[1], run[1] + run[2]};
+                b.rng[A] = pi;
+                b.p0 = run[0];
+            }
+            out.push_back(b);
+        }
+    }
+    static size_t numel(const Block& b) { size_t n = 1; for (int ax = 0; ax < 3; ax++) n *= (size_t)(b.rng[ax].hi - b.rng[ax].lo); return n; }
+};
+
+} // namespace
+
+// cur: this rank's slab of the partition along A, laid out in A's orientation (own A-range outermost).  Fills `stack`
+// (orientation of B, n_loc + 2 r slices) from the slabs of all ranks: pack into the receiver's orientation, one batched
+// group of messages, unpack with row-contiguous strided copies.
+static int shard_exchange(fdn_ctx* h, const ShardPlan& pl, const fdn_comm* comm, const float* cur, int A, int B, int r, bool wrap,
+                          float* stack, int Hs, int Ws)
+{
+    const int me = pl.rank, world = pl.world;
+    const int* oa = ORIENT[A];
+    const int* ob = ORIENT[B];
+    const Range mineA = pl.part(A, me);
+    int64_t stride_cur[3];                                   // element strides of `cur` per GLOBAL axis
+    stride_cur[oa[0]] = (int64_t)pl.N[oa[1]] * pl.N[oa[2]];
+    stride_cur[oa[1]] = pl.N[oa[2]];
+    stride_cur[oa[2]] = 1;
+    std::vector<std::vector<Block>> sends(world), recvs(world);
+    size_t n_send = 0, n_recv = 0;
+    for (int j = 0; j < world; j++) {
+        pl.blocks(A, B, r, wrap, me, j, sends[j]);
+        pl.blocks(A, B, r, wrap, j, me, recvs[j]);
+        for (auto& b : sends[j]) n_send += ShardPlan::numel(b);
+        if (j != me) for (auto& b : recvs[j]) n_recv += ShardPlan::numel(b);
+    }
+    if (ensure(h, h->sh_send, std::max<size_t>(n_send, 1) * sizeof(float)) || ensure(h, h->sh_recv, std::max<size_t>(n_recv, 1) * sizeof(float))) return -1;
+    float* sendbuf = (float*)h->sh_send.p;
+    float* recvbuf = (float*)h->sh_recv.p;
+    std::vector<size_t> send_off(world + 1, 0), recv_off(world + 1, 0);
+    {   // 1. pack every block into the receiver's orientation
+        ScopedTimer t(h, FDN_TIMER_PERMUTE);
+        size_t off = 0;
+        for (int j = 0; j < world; j++) {
+            send_off[j] = off;
+            for (auto& b : sends[j]) {
+                int64_t base = 0;
+                for (int ax = 0; ax < 3; ax++) base += (int64_t)(b.rng[ax].lo - (ax == A ? mineA.lo : 0)) * stride_cur[ax];
+                const int d0 = b.rng[ob[0]].hi - b.rng[ob[0]].lo, d1 = b.rng[ob[1]].hi - b.rng[ob[1]].lo, d2 = b.rng[ob[2]].hi - b.rng[ob[2]].lo;
+                launch_permute(cur + base, sendbuf + off, d0, d1, d2, stride_cur[ob[0]], stride_cur[ob[1]], stride_cur[ob[2]], h->stream);
+                off += (size_t)d0 * d1 * d2;
+            }
+        }
+        send_off[world] = off;
+        FDN_HIP(hipGetLastError());
+    }
+    {   // 2. one batched group of point-to-point messages: every pair at once
+        size_t off = 0;
+        std::vector<fdn_msg> msgs;
+        for (int i = 0; i < world; i++) {
+            recv_off[i] = off;
+            if (i == me) continue;
+            size_t n = 0;
+            for (auto& b : recvs[i]) n += ShardPlan::numel(b);
+            if (n) msgs.push_back({recvbuf + off, n * sizeof(float), i, 0});
+            off += n;
+        }
+        recv_off[world] = off;
+        for (int j = 0; j < world; j++)
+            if (j != me && send_off[j + 1] > send_off[j]) msgs.push_back({sendbuf + send_off[j], (send_off[j + 1] - send_off[j]) * sizeof(float), j, 1});
+        if (world > 1) {
+            ScopedTimer t(h, FDN_TIMER_COLLECTIVE);
+            if (comm->exchange(comm->ctx, (int)msgs.size(), msgs.data(), (void*)h->stream)) return fail("fdn_comm.exchange failed (pass along axis %d)", B);
+        }
+    }
+    {   // 3. unpack into the stack (the block this rank keeps comes straight from its send buffer)
+        ScopedTimer t(h, FDN_TIMER_PERMUTE);
+        for (int i = 0; i < world; i++) {
+            const float* buf = i == me ? sendbuf + send_off[me] : recvbuf + recv_off[i];
+            size_t off = 0;
+            for (auto& b : recvs[i]) {
+                const int n0 = b.rng[ob[0]].hi - b.rng[ob[0]].lo, n1 = b.rng[ob[1]].hi - b.rng[ob[1]].lo, n2 = b.rng[ob[2]].hi - b.rng[ob[2]].lo;
+                float* dst = stack + ((size_t)b.p0 * Hs + b.rng[ob[1]].lo) * Ws + b.rng[ob[2]].lo;
+                launch_permute(buf + off, dst, n0, n1, n2, (int64_t)n1 * n2, n2, 1, h->stream, (int64_t)Hs * Ws, Ws);
+                off += (size_t)n0 * n1 * n2;
+            }
+        }
+        FDN_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+// numpy's float32 mean of the WHOLE volume (seq:420) from Z-slabs, bit for bit: every 8192-element chunk of the flattened
+// volume is summed (numpy's pairwise order) by the rank that holds its first element; a chunk that straddles a slab
+// boundary gets its missing elements from the following rank; the chunk sums are gathered and accumulated in order.
+static int shard_mean(fdn_ctx* h, const ShardPlan& pl, const fdn_comm* comm, const float* slab, float* mean_out)
+{
+    const int me = pl.rank, world = pl.world;
+    const size_t YX = (size_t)pl.N[1] * pl.N[2], ntot = YX * pl.N[0];
+    std::vector<size_t> starts(world + 1);
+    size_t minlen = ntot;
+    for (int k = 0; k < world; k++) { starts[k] = (size_t)pl.part(0, k).lo * YX; }
+    starts[world] = ntot;
+    for (int k = 0; k < world; k++) minlen = std::min(minlen, starts[k + 1] - starts[k]);
+    const size_t mylen = starts[me + 1] - starts[me];
+    if (world == 1) return fdn_mean_dev(h, slab, ntot, mean_out);
+    if (minlen < 8192) {        // tiny volume: a chunk may span several slabs; gather the whole thing (it is small)
+        size_t m = 0;
+        for (int k = 0; k < world; k++) m = std::max(m, starts[k + 1] - starts[k]);
+        std::vector<float> mine(m, 0.f), all(m * world);
+        FDN_HIP(hipMemcpyAsync(mine.data(), slab, mylen * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        FDN_HIP(hipStreamSynchronize(h->stream));
+        if (comm->allgather_host(comm->ctx, mine.data(), all.data(), m * sizeof(float))) return fail("fdn_comm.allgather_host failed");
+        std::vector<float> whole(ntot);
+        for (int k = 0; k < world; k++) memcpy(whole.data() + starts[k], all.data() + (size_t)k * m, (starts[k + 1] - starts[k]) * sizeof(float));
+        return fdn_mean_host(whole.data(), ntot, mean_out);
+    }
+    auto up = [](size_t v) { return (v + 8191) / 8192 * 8192; };
+    std::vector<size_t> first(world + 1);
+    for (int k = 0; k < world; k++) first[k] = std::min(up(starts[k]), ntot);
+    first[world] = ntot;
+    const size_t head = first[me] - starts[me];              // my leading elements belong to the previous rank's last chunk
+    const size_t tail = first[me + 1] - starts[me + 1];      // elements of my last chunk held by the next rank
+    if (ensure(h, h->sh_tmp, 2 * 8192 * sizeof(float))) return -1;
+    float* tmp = (float*)h->sh_tmp.p;                        // [0, 8192): my last chunk assembled; [8192, ...): the tail received
+    {
+        std::vector<fdn_msg> msgs;
+        if (tail > 0) msgs.push_back({tmp + 8192, tail * sizeof(float), me + 1, 0});
+        if (head > 0) msgs.push_back({const_cast<float*>(slab), head * sizeof(float), me - 1, 1});
+        if (comm->exchange(comm->ctx, (int)msgs.size(), msgs.data(), (void*)h->stream)) return fail("fdn_comm.exchange failed (mean)");
+    }
+    const float* own = slab + head;
+    const size_t nown = mylen - head;
+    std::vector<size_t> per(world);
+    size_t maxper = 1;
+    for (int k = 0; k < world; k++) { per[k] = (first[k + 1] - first[k] + 8191) / 8192; maxper = std::max(maxper, per[k]); }
+    std::vector<float> mine(maxper, 0.f), all(maxper * world);
+    size_t got = 0;
+    if (tail > 0) {
+        const size_t nfull = nown / 8192 * 8192;
+        if (nfull) { if (fdn_np_chunk_sums_dev(h, own, nfull, mine.data())) return -1; got = nfull / 8192; }
+        FDN_HIP(hipMemcpyAsync(tmp, own + nfull, (nown - nfull) * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        FDN_HIP(hipMemcpyAsync(tmp + (nown - nfull), tmp + 8192, tail * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        if (fdn_np_chunk_sums_dev(h, tmp, nown - nfull + tail, mine.data() + got)) return -1;
+        got += (nown - nfull + tail + 8191) / 8192;
+    } else if (nown) {
+        if (fdn_np_chunk_sums_dev(h, own, nown, mine.data())) return -1;
+        got = (nown + 8191) / 8192;
+    }
+    if (got != per[me]) return fail("internal: %zu chunk sums, expected %zu", got, per[me]);
+    if (comm->allgather_host(comm->ctx, mine.data(), all.data(), maxper * sizeof(float))) return fail("fdn_comm.allgather_host failed");
+    float tot = 0.f;
+    for (int k = 0; k < world; k++)
+        for (size_t c = 0; c < per[k]; c++) tot += all[(size_t)k * maxper + c];      // numpy accumulates its chunks left to right in float32
+    *mean_out = tot / (float)ntot;
+    return 0;
+}
+
+static int filter_3d_sharded(fdn_ctx* h, const float* slab_in, float* slab_out, int Z, int Y, int X, const double* const kernels[3],
+                             const int K[3], const fdn_sweep_params* p, const fdn_comm* comm)
+{
+    ShardPlan pl;
+    pl.N[0] = Z; pl.N[1] = Y; pl.N[2] = X; pl.world = comm->world; pl.rank = comm->rank;
+    if (pl.world < 1 || pl.rank < 0 || pl.rank >= pl.world) return fail("bad communicator: rank %d of %d", pl.rank, pl.world);
+    if (pl.world > std::min(Z, std::min(Y, X))) return fail("%d ranks need every axis >= %d", pl.world, pl.world);
+    const bool wrap = p->border_mode == FDN_BORDER_WRAP;
+    float mean = 0.f;
+    if (p->warp_mode == FDN_WARP_F64_PADDED) mean = (float)p->pad64;
+    else if (!wrap && shard_mean(h, pl, comm, slab_in, &mean)) return -1;
+    const float* cur = slab_in;
+    int cur_axis = 0, flip = 0;
+    for (int axis = 0; axis < 3; axis++) {
+        if (!kernels[axis] || K[axis] <= 0) continue;
+        if (check_params(p, K[axis])) return -1;
+        const int r = K[axis] / 2;
+        const Range mine = pl.part(axis, pl.rank);
+        const int n_loc = mine.hi - mine.lo, Hs = pl.N[ORIENT[axis][1]], Ws = pl.N[ORIENT[axis][2]];
+        const size_t HW = (size_t)Hs * Ws;
+        if (ensure(h, h->sh_stack, (size_t)(n_loc + 2 * r) * HW * sizeof(float))) return -1;
+        float* stack = (float*)h->sh_stack.p;
+        if (shard_exchange(h, pl, comm, cur, cur_axis, axis, r, wrap, stack, Hs, Ws)) return -1;
+        fdn_sweep_params pp = *p;
+        pp.pad_lo = pp.pad_hi = 0;
+        if (!wrap) {             // stack positions whose slice lies outside the volume (seq:88-89)
+            const int lo = std::max(0, r - mine.lo);
+            const int hi = std::min(n_loc + 2 * r, pl.N[axis] - mine.lo + r);
+            if (lo > 0) launch_fill(stack, mean, (size_t)lo * HW, h->stream);
+            if (hi < n_loc + 2 * r) launch_fill(stack + (size_t)hi * HW, mean, (size_t)(n_loc + 2 * r - hi) * HW, h->stream);
+            pp.pad_lo = lo; pp.pad_hi = n_loc + 2 * r - hi;
+        }
+        DevBuf& ob = h->sh_out[flip];
+        if (ensure(h, ob, (size_t)n_loc * HW * sizeof(float))) return -1;
+        if (sweep_stack(h, stack, (float*)ob.p, n_loc, Hs, Ws, kernels[axis], K[axis], &pp)) return -1;
+        cur = (const float*)ob.p; cur_axis = axis; flip ^= 1;
+    }
+    const Range mz = pl.part(0, pl.rank);
+    if (cur_axis != 0) {         // back to Z-slabs: the same exchange with no halo
+        if (shard_exchange(h, pl, comm, cur, cur_axis, 0, 0, false, slab_out, Y, X)) return -1;
+    } else if (cur != slab_out) {
+        FDN_HIP(hipMemcpyAsync(slab_out, cur, (size_t)(mz.hi - mz.lo) * Y * X * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    }
+    FDN_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---- exported C ABI ---------------------------------------------------------------
 extern "C" {
 
@@ -1611,6 +1868,17 @@ FDN_API int fdn_mean_dev(fdn_handle h, const float* d_in, size_t count, float* m
     for (float v : sums) tot += v;     // numpy accumulates its buffered chunks left to right in float32
     *mean_out = tot / (float)count;
     return 0;
+}
+
+FDN_API int fdn_filter_3d_sharded(fdn_handle h, const float* d_slab_in, float* d_slab_out, int Z, int Y, int X,
+                                  const double* const kernels[3], const int K[3], const fdn_sweep_params* p, const fdn_comm* comm)
+{
+    FDN_ENTER(h);
+    if (!d_slab_in || !d_slab_out || !kernels || !K || !p || !comm) return fail("NULL pointer");
+    if (!comm->exchange || !comm->allgather_host) return fail("fdn_comm needs both callbacks");
+    if (Z <= 0 || Y <= 0 || X <= 0) return fail("bad volume dims");
+    if (d_slab_in == d_slab_out) return fail("in and out must not alias");
+    return filter_3d_sharded(h, d_slab_in, d_slab_out, Z, Y, X, kernels, K, p, comm);
 }
 
 FDN_API int fdn_sweep_stack_dev(fdn_handle h, const float* d_stack, float* d_out, int S, int H, int W,

@@ -128,6 +128,54 @@ class SlabPlan:
         return [tuple(x) for x in runs]
 
 
+class TorchComm:
+    """The two callbacks of fdn_filter_3d_sharded (include/flowdn.h: fdn_comm) over torch.distributed: with the `nccl`
+    backend (RCCL) the device buffers go into one batched group of isend / irecv as they are; with `gloo` (CPU tests,
+    rehearsals of several ranks on one GPU) they are staged through the host.  The C++ engine behind that entry point
+    runs the same schedule as SlabEngine below."""
+
+    def __init__(self, dist, device):
+        import torch
+        self.torch, self.dist, self.device = torch, dist, device
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    class _Ptr:
+        def __init__(self, ptr, nbytes):
+            self.__cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+    def _view(self, ptr, nbytes):
+        return self.torch.as_tensor(self._Ptr(ptr, nbytes), device=self.device)
+
+    def exchange(self, msgs, stream):
+        torch, dist = self.torch, self.dist
+        if not msgs:
+            return
+        views = [(self._view(p, n), peer, snd) for p, n, peer, snd in msgs]
+        s = torch.cuda.ExternalStream(int(stream or 0), device=self.device) if stream else torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(s):
+            if dist.get_backend() == "nccl":
+                ops = [dist.P2POp(dist.isend if snd else dist.irecv, t, peer) for t, peer, snd in views]
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            else:
+                host = [(t.cpu() if snd else torch.empty(t.shape, dtype=t.dtype), t, peer, snd) for t, peer, snd in views]
+                ops = [dist.P2POp(dist.isend if snd else dist.irecv, ht, peer) for ht, _, peer, snd in host]
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+                for ht, t, _, snd in host:
+                    if not snd:
+                        t.copy_(ht)
+            s.synchronize()
+
+    def allgather_host(self, send):
+        torch, dist = self.torch, self.dist
+        mine = torch.frombuffer(bytearray(send), dtype=torch.uint8)
+        dev = self.device if dist.get_backend() == "nccl" else "cpu"
+        got = [torch.empty(mine.numel(), dtype=torch.uint8, device=dev) for _ in range(self.world)]
+        dist.all_gather(got, mine.to(dev))
+        return b"".join(bytes(g.cpu().numpy().tobytes()) for g in got)
+
+
 class HipBackend:
     """Pass compute in libflowdn.so on torch CUDA tensors (device pointers through the C ABI)."""
 

@@ -236,6 +236,41 @@ int fdn_convert_dev(fdn_handle h, const void* d_src, int depth, float* d_dst, si
  * d_dst must not overlap d_src. */
 int fdn_truncate_dev(fdn_handle h, const float* d_src, int depth, void* d_dst, size_t count);
 
+/* ---- the sharded filter below the ABI (SURVEY 8b put multi-GPU under fdn_filter_3d) -------------------------
+ * OF_filter / no_OF_filter (seq:419-431) of a volume held as Z-slabs, one rank per GPU: `d_slab_in` is this rank's slab
+ * of the near-equal contiguous split of Z over comm->world ranks (rank r holds slices [r Z / world ...): base = Z / world
+ * slices, the first Z % world ranks one more -- src/flowdenoising.py:181-206 splits its chunks the same way), `d_slab_out`
+ * receives the filtered slab of the same partition.  Every pass shards along its own axis: Z-slabs -> Z pass -> Y-slabs
+ * -> Y pass -> X-slabs -> X pass -> Z-slabs, ONE exchange per pass delivering partition and K//2 halos together; volume
+ * ends are padded with the global mean (seq:88, seq:420: numpy's float32 mean of the whole volume, assembled from the
+ * ranks' chunk sums) or wrap around (par:312).  The library owns schedule, packing (fdn_permute_dev's kernels) and the
+ * passes; the CALLER owns the communicator and supplies two callbacks:
+ *   exchange        one batched group of point-to-point messages on DEVICE buffers, all of them at once: with RCCL
+ *                   ncclGroupStart(); ncclSend / ncclRecv per message on `stream`; ncclGroupEnd();  with MPI
+ *                   hipStreamSynchronize(stream), MPI_Isend / MPI_Irecv per message, MPI_Waitall.  Every rank calls it
+ *                   the same number of times; a rank with nothing to move in a round passes n = 0.  No message to
+ *                   oneself ever occurs.  Return 0 on success.
+ *   allgather_host  every rank contributes `bytes` from `send` (HOST memory); `recv` (HOST, world * bytes) receives all
+ *                   contributions in rank order (ncclAllGather on a staging buffer, MPI_Allgather, ...).
+ * The Python engine flowdenoising_amd/distributed.py (torch.distributed) implements the same schedule above the ABI;
+ * the two give the same bits.  Integer-volume modes (fdn_sweep_params.warp_mode) are supported with pad64 given by the
+ * caller; otherwise the mean is computed here. */
+typedef struct fdn_msg {
+    void* d_buf;        /* DEVICE memory of this rank */
+    size_t bytes;
+    int peer;           /* the other rank */
+    int is_send;        /* 1: send d_buf to peer, 0: receive from peer into d_buf */
+} fdn_msg;
+typedef struct fdn_comm {
+    void* ctx;
+    int rank, world;
+    int (*exchange)(void* ctx, int n, const fdn_msg* msgs, void* stream);
+    int (*allgather_host)(void* ctx, const void* send, void* recv, size_t bytes);
+} fdn_comm;
+int fdn_filter_3d_sharded(fdn_handle h, const float* d_slab_in, float* d_slab_out, int Z, int Y, int X,
+                          const double* const kernels[3], const int K[3], const fdn_sweep_params* p,
+                          const fdn_comm* comm);
+
 /* ---- slab primitives (multi-GPU decomposition; the reviewer variant
  *      tests/flowdenoising_reviewer_solution2.py:496-508 keeps "chunk + kernel.size"
  *      slices resident the same way) ------------------------------------------------- */

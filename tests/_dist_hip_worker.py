@@ -42,6 +42,14 @@ def main():
     np.save(f"{out_path}.{rank}.npy", out)
     if rank == 0:
         np.save(f"{out_path}.gathered.npy", full.cpu().numpy())
+    # the same job through the C-level entry point (fdn_filter_3d_sharded): schedule, packing and mean in libflowdn.so,
+    # the transport behind the two fdn_comm callbacks (TorchComm: RCCL, or gloo staged through the host)
+    from flowdenoising_amd.distributed import TorchComm
+    res = torch.empty_like(slab)
+    torch.cuda.synchronize()
+    h.filter_3d_sharded(slab.data_ptr(), res.data_ptr(), vol.shape, kernels, params, TorchComm(dist, dev))
+    h.synchronize()
+    np.save(f"{out_path}.c.{rank}.npy", res.cpu().numpy())
     if rank == 0:
         np.save(f"{out_path}.mean.npy", np.float32(mean))
         print("backend", dist.get_backend(), "world", dist.get_world_size(), "phases", {k: round(v, 2) for k, v in eng.phase_times().items()}, flush=True)

@@ -151,6 +151,9 @@ def test_slab_engine_on_hip_backend_multi_rank(fdn, tmp_path, world, shape, sig,
     want = fdn.OF_filter(vol, ks, l, 5, border_mode=border)
     assert np.array_equal(got, want)
     assert np.load(f"{tmp_path}/o.mean.npy") == vol.mean()
+    # the C-level entry point fdn_filter_3d_sharded (schedule and mean in libflowdn.so, transport in two callbacks): same bits
+    got_c = np.concatenate([np.load(f"{tmp_path}/o.c.{r}.npy") for r in range(world)])
+    assert np.array_equal(got_c, want)
 
 
 def test_rccl_world_size_1_carries_the_slab_engine(fdn, tmp_path):
@@ -174,6 +177,7 @@ def test_rccl_world_size_1_carries_the_slab_engine(fdn, tmp_path):
     ks = [fdn.get_gaussian_kernel(float(s)) for s in sig.split(",")]
     want = fdn.OF_filter(vol, ks, 0, 5)
     assert np.array_equal(np.load(f"{tmp_path}/o.0.npy"), want)
+    assert np.array_equal(np.load(f"{tmp_path}/o.c.0.npy"), want)             # fdn_filter_3d_sharded, one rank
     assert np.array_equal(np.load(f"{tmp_path}/o.gathered.npy"), want)
     assert np.load(f"{tmp_path}/o.mean.npy") == vol.mean()
 
