@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--winsize", type=int, default=5, help="Farneback window (-w); configs[4] uses 15")
     ap.add_argument("--integer", choices=("", "seq", "par"), default="", help="time the integer-volume semantics instead (not the headline): "
                     "seq = float64 padded volume, par = integer images; N = 1 only")
+    ap.add_argument("--engine", choices=("python", "c"), default="python", help="N > 1: the slab engine above the C ABI (distributed.py) "
+                    "or fdn_filter_3d_sharded below it (transport through distributed.TorchComm)")
     ap.add_argument("--path", type=int, default=0, help="fdn_set_option path: 0 auto, 1 staged, 2 per-iteration kernels")
     ap.add_argument("--cpu-targets", type=int, default=0, help="target slices of the CPU sample (0 = four per core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -344,12 +346,21 @@ def main():
         plan = fd.SlabPlan(shape, world, rank)
         vol = synth.make_volume(shape, seed=1234 + 3, amplitude=a.amplitude, xp=torch, device=dev,
                                 z0=plan.z0, zlen=plan.zlen)
-        eng = fd.SlabEngine(plan, h, dist)
+        if a.engine == "c":
+            comm = fd.TorchComm(dist, dev)
+            out_slab = torch.empty_like(vol)
 
-        def step():
-            return eng.filter_3d(vol, kernels, params)
+            def step():
+                h.filter_3d_sharded(vol.data_ptr(), out_slab.data_ptr(), shape, kernels, params, comm)
+                return None
+        else:
+            eng = fd.SlabEngine(plan, h, dist)
+
+            def step():
+                return eng.filter_3d(vol, kernels, params)
         out = None
-        parallelism = f"{world} Z-slabs, one exchange per pass (halos + repartition, point-to-point over RCCL)"
+        parallelism = f"{world} Z-slabs, one exchange per pass (halos + repartition, point-to-point over RCCL)" + (
+            "; engine below the C ABI (fdn_filter_3d_sharded)" if a.engine == "c" else "")
         if rehearsal:
             parallelism = f"REHEARSAL: {world} ranks sharing one GPU, exchanges staged through the host over gloo (not a measurement)"
 

@@ -50,6 +50,17 @@ def main():
     h.filter_3d_sharded(slab.data_ptr(), res.data_ptr(), vol.shape, kernels, params, TorchComm(dist, dev))
     h.synchronize()
     np.save(f"{out_path}.c.{rank}.npy", res.cpu().numpy())
+    if loopback:
+        # TorchComm's own plumbing on the real backend: raw device pointers wrapped as tensors, the handle's stream, one
+        # batched group with a send to self and its receive (RCCL with one rank), the host all-gather
+        comm = TorchComm(dist, dev)
+        a = torch.arange(1 << 16, dtype=torch.float32, device=dev) * 0.5
+        bt = torch.zeros_like(a)
+        torch.cuda.synchronize()
+        comm.exchange([(bt.data_ptr(), bt.numel() * 4, rank, False), (a.data_ptr(), a.numel() * 4, rank, True)], torch.cuda.current_stream().cuda_stream)
+        assert torch.equal(a, bt)
+        blob = bytes(range(200)) * 3
+        assert comm.allgather_host(blob) == blob * world
     if rank == 0:
         np.save(f"{out_path}.mean.npy", np.float32(mean))
         print("backend", dist.get_backend(), "world", dist.get_world_size(), "phases", {k: round(v, 2) for k, v in eng.phase_times().items()}, flush=True)
