@@ -520,7 +520,8 @@ static int ensure_flow_pyramid(fdn_ctx* h, std::vector<PyrLevel>& lv, int n, int
 // coarsest reads the next coarser level's flow and upsamples it on the fly (INTER_LINEAR x 2).
 // `prev` (n x H x W x 2) is the previous step's flow or nullptr; out0 receives this step's (or nullptr).
 static int pyramid_step_fused(fdn_ctx* h, const std::vector<PyrLevel>& lv, const float* R0, const float* stack, const float* prev,
-                              float* out0, float* acc, PairBatch pb, int H, int W, int winsize, int iters, double weight)
+                              float* out0, float* acc, PairBatch pb, int H, int W, int winsize, int iters, double weight,
+                              const WarpMode& wm = WarpMode())
 {
     const int L = (int)lv.size() - 1;
     float* fp = (float*)h->flow_pyr.p;
@@ -541,7 +542,7 @@ static int pyramid_step_fused(fdn_ctx* h, const std::vector<PyrLevel>& lv, const
         fin = b; ch = lv[k].h; cw = lv[k].w;
     }
     ScopedTimer t(h, FDN_TIMER_FUSED);
-    launch_farneback_fused(R0, stack, fin, out0, acc, pb, H, W, winsize, iters, weight, h->stream, h->tn, ch, cw);
+    launch_farneback_fused(R0, stack, fin, out0, acc, pb, H, W, winsize, iters, weight, h->stream, h->tn, ch, cw, wm);
     return 0;
 }
 
@@ -568,7 +569,7 @@ static size_t sweep_flow_px(int path, int r, bool pyramid)
 // (one of them, or nullptr) holds the previous step's flow.  *result = where this step's flow is (when keep).
 static int chain_step_iter(fdn_ctx* h, const std::vector<PyrLevel>& lv, const float* R0, const float* stack, const float* prev,
                            float* const bufs[2], float* acc, PairBatch pb, int H, int W, int winsize, int iters, double weight,
-                           bool keep, float** result)
+                           bool keep, float** result, const WarpMode& wm = WarpMode())
 {
     const int L = (int)lv.size() - 1;
     float* fp = (float*)h->flow_pyr.p;
@@ -590,7 +591,7 @@ static int chain_step_iter(fdn_ctx* h, const std::vector<PyrLevel>& lv, const fl
             float* fout = fin == A ? B : A;
             ScopedTimer t(h, FDN_TIMER_ITER);
             if (launch_farneback_iter(Rk, stack, fin, last && !keep ? nullptr : fout, last ? acc : nullptr, pb, lv[k].h, lv[k].w,
-                                      winsize, weight, h->stream, ch, cw))
+                                      winsize, weight, h->stream, ch, cw, wm))
                 return fail("k_farneback_iter could not be launched (winsize %d needs %zu bytes of LDS)", winsize, iter_lds_bytes(winsize / 2, true));
             fin = fout; ch = cw = 0;
         }
@@ -611,7 +612,8 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
     if (p->warp_mode == FDN_WARP_F64_PADDED && (long)p->pad_lo + p->pad_hi > (long)S + 2 * r)
         return fail("pad_lo + pad_hi = %d + %d exceeds the stack's %d slices", p->pad_lo, p->pad_hi, S + 2 * r);
     const WarpMode wm_all = warp_mode_of(p, S, r);   // pad slices in the coordinates of the whole stack
-    const bool plain = wm_all.kind == FDN_WARP_F32;  // otherwise: flows from the Farneback kernels, folding by k_sweep_side
+    // (an integer volume's accumulate -- float64 padded volume / integer images -- is part of the Farneback kernels' final
+    //  stage too: fold_warped<WM>; only the per-stage path folds with k_sweep_side)
 
     if (!p->use_of) { // seq:184-185: taps in index order
         if (h->reserve_only) return 0;
@@ -720,29 +722,15 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
                 for (int step = 0; step < r; step++) {
                     int d = side == 0 ? -(step + 1) : (step + 1); // nearest neighbour first (seq:95,110)
                     bool keep = p->chained && step + 1 < r;       // the next step is seeded with this flow (seq:98)
-                    if (!plain) {   // the flow only; the neighbour is sampled and folded in by k_sweep_side in the volume's mode
-                        if (pyramid) {
-                            if (pyramid_step_fused(h, lv, R, stack, fin, fout, nullptr, PairBatch{n, r + c0, d}, H, W, p->winsize, p->iters, 0.0)) return -1;
-                        } else {
-                            ScopedTimer t(h, FDN_TIMER_FUSED);
-                            launch_farneback_fused(R, stack, fin, fout, nullptr, PairBatch{n, r + c0, d}, H, W, p->winsize, p->iters, 0.0, st, h->tn);
-                        }
-                        {
-                            ScopedTimer t(h, FDN_TIMER_WARP);
-                            launch_sweep_side(stack, fout, acc, PairBatch{n, r + c0, side == 0 ? -1 : 1}, 1, step, H, W, &kernel[r + d], st, wm);
-                        }
-                        if (keep) { fin = fout; fout = fout == flow ? flowB : flow; }
-                        continue;
-                    }
                     if (pyramid) {
                         if (pyramid_step_fused(h, lv, R, stack, fin, keep ? fout : nullptr, acc, PairBatch{n, r + c0, d}, H, W,
-                                               p->winsize, p->iters, kernel[r + d])) return -1;
+                                               p->winsize, p->iters, kernel[r + d], wm)) return -1;
                         if (keep) { fin = fout; fout = fout == flow ? flowB : flow; }
                         continue;
                     }
                     ScopedTimer t(h, FDN_TIMER_FUSED);
                     launch_farneback_fused(R, stack, fin, keep ? fout : nullptr, acc, PairBatch{n, r + c0, d}, H, W,
-                                           p->winsize, p->iters, kernel[r + d], st, h->tn);
+                                           p->winsize, p->iters, kernel[r + d], st, h->tn, 0, 0, wm);     // wm: an integer volume's own accumulate
                     if (keep) { fin = fout; fout = fout == flow ? flowB : flow; }
                 }
                 continue;
@@ -754,15 +742,8 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
                     int d = side == 0 ? -(step + 1) : (step + 1);
                     bool keep = p->chained && step + 1 < r;
                     float* res = nullptr;
-                    if (!plain) {
-                        if (chain_step_iter(h, lv, R, stack, prev, bufs, nullptr, PairBatch{n, r + c0, d}, H, W, p->winsize, p->iters, 0.0, true, &res)) return -1;
-                        ScopedTimer t(h, FDN_TIMER_WARP);
-                        launch_sweep_side(stack, res, acc, PairBatch{n, r + c0, side == 0 ? -1 : 1}, 1, step, H, W, &kernel[r + d], st, wm);
-                        prev = keep ? res : nullptr;
-                        continue;
-                    }
                     if (chain_step_iter(h, lv, R, stack, prev, bufs, acc, PairBatch{n, r + c0, d}, H, W, p->winsize, p->iters,
-                                        kernel[r + d], keep, &res)) return -1;
+                                        kernel[r + d], keep, &res, wm)) return -1;
                     prev = keep ? res : nullptr;
                 }
                 continue;

@@ -370,6 +370,23 @@ static __device__ __forceinline__ double remap_sample_f64(const double* __restri
     return src[oa + xa] * (double)w0 + src[oa + xb] * (double)w1 + src[ob + xa] * (double)w2 + src[ob + xb] * (double)w3;
 }
 
+// acc <- f32(f64(acc) + warp_slice(neighbour, flow) * weight) (seq:106-107) in the semantics the volume's dtype gives the
+// reference (fdn_sweep_params.warp_mode; WarpMode of fdn_internal.h):
+//   0  float32 volume
+//   1  seq on an integer MRC: the padded volume is float64 (seq:88-89): cv2.remap's CV_64F path (table weights widened,
+//      products and sums in double, no rounding to float); `pad`: the neighbour is a pad slice, the constant float64 mean
+//   2  par on an integer MRC: the neighbour is an integer image: remap rounds half to even and saturates (lo, hi)
+template <int WM>
+static __device__ __forceinline__ float fold_warped(const float* __restrict__ src, int H, int W, int x, int y, float2 f, float acc_old,
+                                                    double weight, bool pad, double pad64, float lo, float hi)
+{
+    RemapTaps r;
+    remap_issue<false>(src, H, W, x, y, f, r);
+    if (WM == 1) return (float)((double)acc_old + remap_finish_f64(r, pad, pad64) * weight);
+    if (WM == 2) return (float)((double)acc_old + (double)fminf(fmaxf(rintf(remap_finish(r)), lo), hi) * weight);
+    return (float)((double)acc_old + (double)remap_finish(r) * weight);
+}
+
 static __device__ __forceinline__ float remap_sample(const float* __restrict__ src, int H, int W, int x, int y, float2 f)
 {
     RemapTaps r;

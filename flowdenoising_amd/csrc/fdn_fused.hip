@@ -82,13 +82,13 @@ static __device__ __forceinline__ void lds_barrier()
 // per CU: the same sixteen waves and LDS per CU as four one-band workgroups, 3 % faster on large grids (17.06 against
 // 17.58 ms per launch, same box) -- the two bands are neighbours in the image and stay in step, so the columns they share
 // and the R1 rows both stream arrive once per CU.
-template <int MH, int D, int DX, int U, int OCC, int FIN, bool ACC, int NB>
+template <int MH, int D, int DX, int U, int OCC, int FIN, bool ACC, int NB, int WM = 0>
 // (the second argument of __launch_bounds__ is waves per SIMD: for a 4-wave workgroup that is workgroups per CU; the
 // 8-wave workgroup runs two per CU, i.e. the same 4)
 __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused(const float* __restrict__ Rstack, const float* __restrict__ stack,
                                                          const float* __restrict__ flow_in_base, float* __restrict__ flow_out_base,
                                                          float* __restrict__ acc_base, PairBatch pb, int H, int W,
-                                                         double scale, double weight, int nbands, FlowSource fs)
+                                                         double scale, double weight, int nbands, FlowSource fs, WarpMode wm)
 {
     constexpr int ITERS = 3;
     constexpr int STEP = MH + 1;                 // row stagger between stages
@@ -390,8 +390,10 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
 #pragma unroll
                             for (int c = 0; c < 5; c++) Mx[K < ITERS ? K : 0][y & 1][c][lane] = mm[c];
                         } else if (ACC) {
-                            const float warped = remap_sample(img1, H, W, xc, y, f);
-                            const float acc_new = (float)((double)acc_old + (double)warped * weight);
+                            // (WM: the dtype semantics of an integer volume, fold_warped in fdn_device.h; the neighbour's stack index decides `pad`)
+                            const int q = pb.t0 + b + pb.d;
+                            const float acc_new = fold_warped<WM>(img1, H, W, xc, y, f, acc_old, weight, WM == 1 && (q < wm.pad_lo || q >= wm.pad_hi),
+                                                                  wm.pad64, wm.lo, wm.hi);
                             if (owner) {
                                 if (flow_out) st_off(flow_out, o * 8u, f);
                                 st_off(acc, o * 4u, acc_new);
@@ -458,7 +460,7 @@ template <> struct FusedVariant<4, 3> { static constexpr int D = 7, DX = 6, U = 
 
 template <int MH, int OCC, int NB = 1>
 static void launch_variant(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
-                           PairBatch pb, int H, int W, double scale, double weight, FlowSource fs, hipStream_t st, unsigned lds_pad)
+                           PairBatch pb, int H, int W, double scale, double weight, FlowSource fs, hipStream_t st, unsigned lds_pad, const WarpMode& wm)
 {
     constexpr int D = FusedVariant<MH, OCC>::D, DX = FusedVariant<MH, OCC>::DX, U = FusedVariant<MH, OCC>::U;
     constexpr int WC = 64 + 2 * DX, WCP = FDN_WIN_QUAD ? WC : (5 * WC) % 16 == 0 ? WC + 2 : WC;   // as in the kernel
@@ -480,10 +482,18 @@ static void launch_variant(const float* Rstack, const float* stack, const float*
                 told.push_back(key);
             }
         }
-        hipLaunchKernelGGL(kern, grid, dim3(256 * NB), lds, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, fs);
+        hipLaunchKernelGGL(kern, grid, dim3(256 * NB), lds, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, fs, wm);
     };
     const int fin = !flow_in ? 0 : fs.h > 0 ? 2 : 1;
-    if (acc) {
+    if (acc && wm.kind == 1) {          // integer volumes (fdn_sweep_params.warp_mode): the accumulate in their own semantics
+        if (fin == 2) launch(k_farneback_fused<MH, D, DX, U, OCC, 2, true, NB, 1>);
+        else if (fin == 1) launch(k_farneback_fused<MH, D, DX, U, OCC, 1, true, NB, 1>);
+        else launch(k_farneback_fused<MH, D, DX, U, OCC, 0, true, NB, 1>);
+    } else if (acc && wm.kind == 2) {
+        if (fin == 2) launch(k_farneback_fused<MH, D, DX, U, OCC, 2, true, NB, 2>);
+        else if (fin == 1) launch(k_farneback_fused<MH, D, DX, U, OCC, 1, true, NB, 2>);
+        else launch(k_farneback_fused<MH, D, DX, U, OCC, 0, true, NB, 2>);
+    } else if (acc) {
         if (fin == 2) launch(k_farneback_fused<MH, D, DX, U, OCC, 2, true, NB>);
         else if (fin == 1) launch(k_farneback_fused<MH, D, DX, U, OCC, 1, true, NB>);
         else launch(k_farneback_fused<MH, D, DX, U, OCC, 0, true, NB>);
@@ -510,7 +520,7 @@ static int choose_occupancy(long blocks, const Tuning& tn)
 // coarse_h, coarse_w > 0: flow_in holds the next coarser level's flow of that size (upsampled in the kernel).
 void launch_farneback_fused(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
                             PairBatch pb, int H, int W, int winsize, int iters, double weight, hipStream_t st,
-                            const Tuning& tn, int coarse_h, int coarse_w)
+                            const Tuning& tn, int coarse_h, int coarse_w, const WarpMode& wm)
 {
     if (pb.npairs <= 0) return;
     (void)iters;
@@ -518,20 +528,20 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
     const double scale = 1. / ((double)winsize * winsize);
     const int mh = winsize / 2;
 #ifndef FDN_ONLY_MH2   // (experiment builds leave the other windows out: half the compile time)
-    if (mh == 1) { launch_variant<1, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad); return; }
-    if (mh == 3) { launch_variant<3, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad); return; }
-    if (mh == 4) { launch_variant<4, 3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad); return; }
+    if (mh == 1) { launch_variant<1, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad, wm); return; }
+    if (mh == 3) { launch_variant<3, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad, wm); return; }
+    if (mh == 4) { launch_variant<4, 3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad, wm); return; }
 #endif
     const int BW = 64 - 2 * 2 * 3;
     const long blocks = (long)((W + BW - 1) / BW) * pb.npairs;
     switch (choose_occupancy(blocks, tn)) {
-    case 3: launch_variant<2, 3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad); break;
-    case 5: launch_variant<2, 5>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad); break;
+    case 3: launch_variant<2, 3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad, wm); break;
+    case 5: launch_variant<2, 5>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad, wm); break;
     default:
         // tn.fused_occ = 8: two bands per workgroup (the same 4 bands per CU, less HBM traffic; the default until the
         // edge bands lost their ds_bpermute path -- since then one band per workgroup is 2 % faster on large grids too)
-        if (tn.fused_occ == 8) launch_variant<2, 4, 2>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad);
-        else launch_variant<2, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad);
+        if (tn.fused_occ == 8) launch_variant<2, 4, 2>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad, wm);
+        else launch_variant<2, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad, wm);
         break;
     }
 }

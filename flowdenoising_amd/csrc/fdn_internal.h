@@ -92,7 +92,7 @@ struct Tuning {
 bool fused_supported(int winsize, int iters, int H, int W);
 void launch_farneback_fused(const float* Rstack, const float* stack, const float* flow_in, float* flow_out,
                             float* acc, PairBatch pb, int H, int W, int winsize, int iters, double weight,
-                            hipStream_t st, const Tuning& tn, int coarse_h = 0, int coarse_w = 0);
+                            hipStream_t st, const Tuning& tn, int coarse_h = 0, int coarse_w = 0, const WarpMode& wm = WarpMode());
 
 // One Farneback iteration per launch, any window (fdn_iter.hip): flow_out = solve(box_w(UpdateMatrices(flow_in)));
 // acc != nullptr: also acc += weight * remap(stack[n], flow_out) (the last iteration of the finest level; flow_out may
@@ -102,7 +102,7 @@ bool iter_supported(int winsize, int H, int W);
 size_t iter_lds_bytes(int mh, bool acc);
 int launch_farneback_iter(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
                           PairBatch pb, int H, int W, int winsize, double weight, hipStream_t st,
-                          int coarse_h = 0, int coarse_w = 0);
+                          int coarse_h = 0, int coarse_w = 0, const WarpMode& wm = WarpMode());
 
 // where the fused kernel's initial flow comes from when it is the next coarser pyramid level's result
 struct FlowSource { int h, w; double sx, sy; };   // h == 0: flow_in has the image's own size

@@ -73,11 +73,11 @@ static __device__ __forceinline__ void lds_barrier_iter()
 // MHT: window half-width when known at compile time (0: runtime mh).  FIN 0: zero initial flow, 1: flow_in has the
 // image's size, 2: flow_in is the next coarser level's (fs.h x fs.w) result, resized INTER_LINEAR and doubled on the fly
 // (calc()'s upsampling).  ACC: also warp the neighbour with the new flow and accumulate.
-template <int MHT, int FIN, bool ACC>
+template <int MHT, int FIN, bool ACC, int WM = 0>
 __global__ __launch_bounds__(ACC ? 192 : 128) void k_farneback_iter(const float* __restrict__ Rstack, const float* __restrict__ stack,
                                                         const float* __restrict__ flow_in_base, float* __restrict__ flow_out_base,
                                                         float* __restrict__ acc_base, PairBatch pb, int H, int W, int mh_rt,
-                                                        double scale, double weight, int nbands, FlowSource fs)
+                                                        double scale, double weight, int nbands, FlowSource fs, WarpMode wm)
 {
     const int MH = MHT ? MHT : mh_rt;
     const int RS = 2 * MH + 2;
@@ -190,8 +190,9 @@ __global__ __launch_bounds__(ACC ? 192 : 128) void k_farneback_iter(const float*
                 const float2 f = fho[(y & 1) * 64 + lane];
                 const unsigned o = (unsigned)y * (unsigned)W + (unsigned)xc;
                 const float acc_old = ld_off<float>(acc, o * 4u);
-                const float warped = remap_sample(img1, H, W, xc, y, f);
-                const float acc_new = (float)((double)acc_old + (double)warped * weight);
+                const int q = pb.t0 + b + pb.d;        // (WM: integer-volume semantics, fold_warped in fdn_device.h)
+                const float acc_new = fold_warped<WM>(img1, H, W, xc, y, f, acc_old, weight, WM == 1 && (q < wm.pad_lo || q >= wm.pad_hi),
+                                                      wm.pad64, wm.lo, wm.hi);
                 if (owner) st_off(acc, o * 4u, acc_new);
             }
             lds_barrier_iter();
@@ -322,7 +323,7 @@ size_t iter_lds_bytes(int mh, bool acc)
 
 template <int MHT>
 static int launch_iter_t(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc, PairBatch pb,
-                         int H, int W, int mh, double scale, double weight, FlowSource fs, hipStream_t st)
+                         int H, int W, int mh, double scale, double weight, FlowSource fs, hipStream_t st, const WarpMode& wm)
 {
     const int BW = 64 - 2 * mh;
     const int nbands = (W + BW - 1) / BW;
@@ -341,9 +342,19 @@ static int launch_iter_t(const float* Rstack, const float* stack, const float* f
                 if (it == told.end()) told.push_back(Told{(const void*)kern, dev, lds}); else it->bytes = lds;
             }
         }
-        hipLaunchKernelGGL(kern, grid, dim3(acc ? 192 : 128), lds, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, nbands, fs);
+        hipLaunchKernelGGL(kern, grid, dim3(acc ? 192 : 128), lds, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, nbands, fs, wm);
         return hipGetLastError() == hipSuccess ? 0 : -1;      // a bad launch configuration is this launch's error, not the next check's
     };
+    if (acc && wm.kind == 1) {
+        if (fin == 2) return launch(k_farneback_iter<MHT, 2, true, 1>);
+        if (fin == 1) return launch(k_farneback_iter<MHT, 1, true, 1>);
+        return launch(k_farneback_iter<MHT, 0, true, 1>);
+    }
+    if (acc && wm.kind == 2) {
+        if (fin == 2) return launch(k_farneback_iter<MHT, 2, true, 2>);
+        if (fin == 1) return launch(k_farneback_iter<MHT, 1, true, 2>);
+        return launch(k_farneback_iter<MHT, 0, true, 2>);
+    }
     if (acc) {
         if (fin == 2) return launch(k_farneback_iter<MHT, 2, true>);
         if (fin == 1) return launch(k_farneback_iter<MHT, 1, true>);
@@ -358,17 +369,17 @@ static int launch_iter_t(const float* Rstack, const float* stack, const float* f
 // coarser level's flow of that size.  acc != nullptr: this is the last iteration of the finest level: warp + accumulate
 // (flow_out may then be nullptr when nobody needs the flow).  flow_in and flow_out must be different buffers.
 int launch_farneback_iter(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
-                          PairBatch pb, int H, int W, int winsize, double weight, hipStream_t st, int coarse_h, int coarse_w)
+                          PairBatch pb, int H, int W, int winsize, double weight, hipStream_t st, int coarse_h, int coarse_w, const WarpMode& wm)
 {
     if (pb.npairs <= 0) return 0;
     FlowSource fs{coarse_h, coarse_w, coarse_h > 0 ? (double)coarse_w / W : 1.0, coarse_h > 0 ? (double)coarse_h / H : 1.0};
     const double scale = 1. / ((double)winsize * winsize);
     const int mh = winsize / 2;
     switch (mh) {   // compile-time windows for the usual sizes; anything else takes the runtime-width build
-    case 2: return launch_iter_t<2>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st);
-    case 5: return launch_iter_t<5>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st);
-    case 7: return launch_iter_t<7>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st);
-    default: return launch_iter_t<0>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st);
+    case 2: return launch_iter_t<2>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st, wm);
+    case 5: return launch_iter_t<5>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st, wm);
+    case 7: return launch_iter_t<7>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st, wm);
+    default: return launch_iter_t<0>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st, wm);
     }
 }
 
