@@ -9,10 +9,10 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
   i=$((i+1))
   timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d gpurun_out/w15_pmc$i -- $B > gpurun_out/w15_pmc$i.log 2>&1 || { echo "set $i failed"; break; }
 done
-python3 tools/pmc_summary.py "gpurun_out/w15_pmc*/**/*_counter_collection.csv" "k_farneback_iter<7, 1, true>" > gpurun_out/w15_pmc_summary.txt
-python3 tools/pmc_summary.py "gpurun_out/w15_pmc*/**/*_counter_collection.csv" "k_farneback_iter<7, 1, false>" >> gpurun_out/w15_pmc_summary.txt
+python3 tools/pmc_summary.py "gpurun_out/w15_pmc*/**/*_counter_collection.csv" "k_farneback_iter<7, 1, true" > gpurun_out/w15_pmc_summary.txt
+python3 tools/pmc_summary.py "gpurun_out/w15_pmc*/**/*_counter_collection.csv" "k_farneback_iter<7, 1, false" >> gpurun_out/w15_pmc_summary.txt
 cat gpurun_out/w15_pmc_summary.txt
 # what bench.py reads: the mean over the launches of every level and kind (its roofline line averages the same way) ...
 python3 tools/make_traffic_json.py "k_farneback_iter<7" gpurun_out/w15_traffic.json ${1:-unknown} "gpurun_out/w15_pmc*/**/*_counter_collection.csv" 3 15
 # ... and the level-0 warping launch on its own (512 x 1024 x 1024 pixels per launch), for DESIGN.md
-python3 tools/make_traffic_json.py "k_farneback_iter<7, 1, true>" gpurun_out/w15_traffic_level0_warp.json ${1:-unknown} "gpurun_out/w15_pmc*/**/*_counter_collection.csv" 0 15
+python3 tools/make_traffic_json.py "k_farneback_iter<7, 1, true" gpurun_out/w15_traffic_level0_warp.json ${1:-unknown} "gpurun_out/w15_pmc*/**/*_counter_collection.csv" 0 15
