@@ -103,7 +103,7 @@ def no_OF_filter_along_X(vol, kernel, mean, device=0):
     return _filter_axis(vol, 2, kernel, 0, OF_WINDOW_SIZE, mean, False, _lib.BORDER_MEAN_PAD, True, device)
 
 
-def integer_semantics(vol, params):
+def integer_semantics(vol, params, mean_on_device=False):
     """What the reference does with a volume that is not float32 (an int8/int16/uint16 MRC keeps its dtype, seq:513,
     par:472), as fdn_sweep_params fields (include/flowdn.h, FDN_WARP_*).  Returns params (a copy when changed).
       mean-padded (seq): vol.mean() is a float64, hence a float64 padded volume (seq:88-89): cv2.remap weights in
@@ -119,7 +119,10 @@ def integer_semantics(vol, params):
     p = params.copy()
     if params.border_mode == _lib.BORDER_MEAN_PAD:
         p.warp_mode = _lib.WARP_F64_PADDED
-        p.pad64 = float(vol.mean())              # seq:420 on an integer array: numpy's float64 mean
+        # seq:420 on an integer array: numpy's float64 mean = (exact integer sum) / count.  mean_on_device: the caller takes
+        # it from the device copy instead (fdn_stats_dev: the float64 sum of 8- or 16-bit integers is exact as well; half a
+        # second of numpy on a 1 GiB int16 tomogram) and fills pad64 in before the first launch
+        p.pad64 = float("nan") if mean_on_device else float(vol.mean())
     else:
         if params.use_of and vol.dtype == np.int8:
             raise ValueError("cv2.remap does not accept 8-bit signed images (the reference fails on a mode-0 MRC here)")
@@ -167,7 +170,7 @@ def filter_3d_own_mean(vol, kernel, params, device=0, stats=None, float32_semant
             tick[0] = now
 
     if not float32_semantics:
-        params = integer_semantics(vol, params)
+        params = integer_semantics(vol, params, mean_on_device=True)
     vol = np.asarray(vol)
     if vol.ndim != 3:
         raise ValueError(f"expected a (Z, Y, X) volume, got shape {vol.shape}")
@@ -197,8 +200,11 @@ def filter_3d_own_mean(vol, kernel, params, device=0, stats=None, float32_semant
             if raw_int:
                 h.convert_dev(d_out, src.dtype, d_in, src.size)      # float32 from there into d_in
             lap("h2d")
+            st_in = h.stats_dev(d_in, src.size) if (stats is not None or params.pad64 != params.pad64) else None
             if stats is not None:
-                stats["in"] = h.stats_dev(d_in, src.size)
+                stats["in"] = st_in
+            if params.pad64 != params.pad64:      # an integer volume's float64 mean (seq:420), exact from the device copy
+                params.pad64 = st_in["mean"]
             # an integer volume's mean is numpy's float64 one (params.pad64); Farneback sees it as float32
             mean = np.float32(params.pad64) if params.warp_mode == _lib.WARP_F64_PADDED else h.mean_dev(d_in, src.size)
             h.filter_3d_dev(d_in, d_out, src.shape, kernel, mean, params)
