@@ -125,7 +125,7 @@ def _reserve(args, shape, dtype, Ks, l, w):
         logging.debug(f"reserve: {e}")
 
 
-def _run_sharded(args, shape, kernels, l, w):
+def _run_sharded(args, shape, kernels, l, w, stats=None):
     """Called under torch.distributed.run (one rank per GPU).  Every rank reads ITS OWN Z-slab of the input file;
     the global mean (seq:420) is assembled from the ranks' chunk sums (numpy's float32 value, bit for bit); the
     filtered slabs are sent to rank 0 only, which writes the output."""
@@ -166,6 +166,9 @@ def _run_sharded(args, shape, kernels, l, w):
     eng = SlabEngine(plan, h, dist)
     out = eng.filter_3d(slab, kernels, params, mean=mean)
     full = eng.gather_z_slabs(out, 0)               # slabs may differ in length: point-to-point into their place, rank 0 only
+    if rank == 0 and stats is not None:             # what the reference logs about the result and mrcfile puts into the header
+        torch.cuda.synchronize()
+        stats["out"] = h.stats_dev(full.data_ptr(), full.numel())
     res = full.cpu().numpy() if rank == 0 else None
     logging.info(f"rank {rank} phases (ms): " + ", ".join(f"{k} {v:.1f}" for k, v in eng.phase_times().items()))
     dist.barrier()
@@ -258,7 +261,7 @@ def main(argv=None):
     state["stage"] = "filtering"
     t0 = time.perf_counter()
     if sharded:
-        filtered = _run_sharded(args, shape, kernels, l, w)
+        filtered = _run_sharded(args, shape, kernels, l, w, stats)
     else:
         filtered = _run_single(args, vol, kernels, l, w, args.device, stats, as_float32, timing=wall,
                                wait_for=prep.join if prep is not None else None)
