@@ -8,9 +8,9 @@ MRC: 1024-byte header (nx, ny, nz, mode at words 1-4; nsymbt extended-header byt
 'MAP ' + machine stamp at bytes 208-215) followed by the raw array; modes 0/1/2/6/12 =
 int8/int16/float32/uint16/float16.  Output is always mode 2 with dmin/dmax/dmean/rms filled in,
 like mrcfile.new(...).set_data(float32) (seq:562-564).
-TIFF: uncompressed, single-sample pages of uint8/uint16/int16/uint32/float32/float64, classic or
-BigTIFF, either byte order; one IFD per page, or an ImageJ hyperstack with one IFD and
-contiguous data.
+TIFF: single-sample pages of uint8/uint16/int16/uint32/float32/float64, uncompressed or deflate-compressed
+(compression 8 / 32946, predictor 1 or 2), classic or BigTIFF, either byte order; one IFD per page, or an
+ImageJ hyperstack with one IFD and contiguous data.
 """
 import os
 import struct
@@ -158,14 +158,21 @@ def read_tiff(path, zrange=None, shape_only=False):
             tags, off = _read_ifd(f, order, off, big)
             if first is None:
                 first = tags
-            if tags.get(259, (1,))[0] != 1:
-                raise ValueError(f"{path}: compressed TIFF (compression {tags[259][0]}) is not supported")
+            comp = tags.get(259, (1,))[0]
+            if comp not in (1, 8, 32946):
+                raise ValueError(f"{path}: TIFF compression {comp} is not supported (uncompressed and deflate are)")
             spp = tags.get(277, (1,))[0]
             if spp != 1 and tags.get(284, (1,))[0] != 2:
                 raise ValueError(f"{path}: interleaved multi-sample (RGB) pages are not volumes")
             W, H = tags[256][0], tags[257][0]
             dt = _page_dtype(tags, order)
             offs, cnts = tags[273], tags.get(279)
+            if comp != 1:  # deflate (zlib) strips, optionally with the horizontal-differencing predictor: decoded when the page is wanted
+                pred = tags.get(317, (1,))[0]
+                if spp != 1 or cnts is None or pred not in (1, 2) or (pred == 2 and dt.kind == "f"):
+                    raise ValueError(f"{path}: this compressed TIFF layout is not supported (samples {spp}, predictor {pred})")
+                pages.append((("deflate", tuple(offs), tuple(cnts), pred), H, W, dt))
+                continue
             if spp != 1:   # planar samples (tifffile stores a 3- or 4-slice stack this way): one plane = one slice
                 if len(offs) != spp:
                     raise ValueError(f"{path}: planar page with several strips per plane is not supported")
@@ -203,6 +210,19 @@ def read_tiff(path, zrange=None, shape_only=False):
         for i, (src, h, w, d) in enumerate(pages):
             if isinstance(src, np.ndarray):
                 out[i] = src
+            elif isinstance(src, tuple):     # deflate strips
+                import zlib
+                _, offs, cnts, pred = src
+                raw = bytearray()
+                for o, c in zip(offs, cnts):
+                    f.seek(o)
+                    raw += zlib.decompress(f.read(c))
+                if len(raw) != H * W * dt.itemsize:
+                    raise ValueError(f"{path}: page {i} decompresses to {len(raw)} bytes, expected {H * W * dt.itemsize}")
+                page = np.frombuffer(bytes(raw), dtype=dt).reshape(H, W)
+                if pred == 2:                # horizontal differencing: running sum along the row, modulo the sample width
+                    page = np.cumsum(page.astype(dt.newbyteorder("=")), axis=1, dtype=dt.newbyteorder("="))
+                out[i] = page
             else:
                 f.seek(src)
                 if dt.isnative:          # straight into its place (np.fromfile would allocate and copy every page)
@@ -216,7 +236,8 @@ def read_tiff(path, zrange=None, shape_only=False):
 class _TiffPages:
     """Page after page of an uncompressed multi-page TIFF: one strip and one IFD per page, little-endian; BigTIFF above 4 GiB."""
 
-    def __init__(self, f, shape, dtype):
+    def __init__(self, f, shape, dtype, deflate=False):
+        self.deflate = bool(deflate)
         dtype = np.dtype(dtype)
         kind = dtype.kind
         if kind not in "uif" or dtype.itemsize not in (1, 2, 4, 8):
@@ -237,7 +258,12 @@ class _TiffPages:
     def write_page(self, page):
         f, big, z, Z, H, W, desc, page_bytes = self.f, self.big, self.z, self.Z, self.H, self.W, self.desc, self.page_bytes
         pos = self.pos
-        entries = [(256, 4, W), (257, 4, H), (258, 3, self.dtype.itemsize * 8), (259, 3, 1), (262, 3, 1)]
+        data = None
+        if self.deflate:
+            import zlib
+            data = zlib.compress(np.ascontiguousarray(page, dtype=self.dtype).tobytes(), 1)
+            page_bytes = len(data)
+        entries = [(256, 4, W), (257, 4, H), (258, 3, self.dtype.itemsize * 8), (259, 3, 8 if self.deflate else 1), (262, 3, 1)]
         if z == 0:
             entries.append((270, 2, desc))
         entries += [(273, 16 if big else 4, None), (277, 3, 1), (278, 4, H), (279, 16 if big else 4, page_bytes),
@@ -269,18 +295,22 @@ class _TiffPages:
         f.seek(pos)
         f.write(buf)
         f.seek(data_off)
-        np.ascontiguousarray(page, dtype=self.dtype).tofile(f)
+        if data is not None:
+            f.write(data)
+        else:
+            np.ascontiguousarray(page, dtype=self.dtype).tofile(f)
         self.pos = next_ifd
         self.z += 1
 
 
-def write_tiff(path, vol):
-    """One uncompressed strip and one IFD per page, little-endian; BigTIFF above 4 GiB."""
+def write_tiff(path, vol, deflate=False):
+    """One strip and one IFD per page, little-endian; BigTIFF above 4 GiB.  deflate: zlib-compressed strips (compression 8;
+    the CLI writes uncompressed pages like the reference's imsave)."""
     vol = np.asarray(vol)
     if vol.ndim == 2:
         vol = vol[None]
     with open(path, "wb") as f:
-        pages = _TiffPages(f, vol.shape, vol.dtype)
+        pages = _TiffPages(f, vol.shape, vol.dtype, deflate=deflate)
         for z in range(vol.shape[0]):
             pages.write_page(vol[z])
     return path

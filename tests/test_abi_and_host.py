@@ -195,3 +195,38 @@ def test_sweep_params_layout_matches_the_header(tmp_path):
     assert got[0] == ctypes.sizeof(_lib.SweepParams)
     assert got[1:] == [getattr(_lib.SweepParams, n).offset for n in names]
     assert (_lib.WARP_F32, _lib.WARP_F64_PADDED, _lib.WARP_ROUND_INT) == (0, 1, 2)
+
+
+def test_tiff_deflate_pages_and_predictor(tmp_path):
+    """Deflate-compressed TIFF stacks (compression 8, what tifffile / Bio-Formats write with `compress`; the reference reads
+    them through skimage.io.imread, seq:517): strips are zlib streams, predictor 2 is a running sum along the row.  Page
+    ranges (a multi-GPU rank's slab) and the page directory alone work without decoding the other pages."""
+    import struct
+    import zlib
+    from flowdenoising_amd import io as fio
+    rng = np.random.default_rng(1)
+    for dt in (np.uint8, np.uint16, np.int16, np.float32):
+        v = (rng.random((5, 33, 47)) * 300).astype(dt)
+        fio.write_tiff(str(tmp_path / "c.tif"), v, deflate=True)
+        assert np.array_equal(fio.read_tiff(str(tmp_path / "c.tif")), v)
+        assert np.array_equal(fio.read_tiff(str(tmp_path / "c.tif"), zrange=(1, 4)), v[1:4])
+        assert fio.read_tiff(str(tmp_path / "c.tif"), shape_only=True)[0] == v.shape
+    v = (rng.random((8, 16)) * 60000).astype(np.uint16)            # one page, two strips, horizontal differencing
+    diff = v.copy()
+    diff[:, 1:] = v[:, 1:] - v[:, :-1]
+    s0, s1 = zlib.compress(diff[:4].tobytes()), zlib.compress(diff[4:].tobytes())
+    ent = [(256, 4, 1, 16), (257, 4, 1, 8), (258, 3, 1, 16), (259, 3, 1, 8), (262, 3, 1, 1), (277, 3, 1, 1), (278, 4, 1, 4), (317, 3, 1, 2), (339, 3, 1, 1)]
+    n = len(ent) + 2
+    ext = 8 + 2 + n * 12 + 4
+    d0 = ext + 16
+    ent = sorted(ent + [(273, 4, 2, ext), (279, 4, 2, ext + 8)])
+    b = b"II" + struct.pack("<HI", 42, 8) + struct.pack("<H", n)
+    for tag, typ, cnt, val in ent:
+        b += struct.pack("<HHI", tag, typ, cnt) + (struct.pack("<H", val).ljust(4, b"\0") if typ == 3 else struct.pack("<I", val))
+    b += struct.pack("<I", 0) + struct.pack("<II", d0, d0 + len(s0)) + struct.pack("<II", len(s0), len(s1)) + s0 + s1
+    (tmp_path / "p.tif").write_bytes(b)
+    assert np.array_equal(fio.read_tiff(str(tmp_path / "p.tif"))[0], v)
+    # LZW stays refused, loudly
+    (tmp_path / "l.tif").write_bytes(b.replace(struct.pack("<HHIHH", 259, 3, 1, 8, 0), struct.pack("<HHIHH", 259, 3, 1, 5, 0)))
+    with pytest.raises(ValueError, match="compression 5"):
+        fio.read_tiff(str(tmp_path / "l.tif"))
