@@ -230,3 +230,30 @@ def test_tiff_deflate_pages_and_predictor(tmp_path):
     (tmp_path / "l.tif").write_bytes(b.replace(struct.pack("<HHIHH", 259, 3, 1, 8, 0), struct.pack("<HHIHH", 259, 3, 1, 5, 0)))
     with pytest.raises(ValueError, match="compression 5"):
         fio.read_tiff(str(tmp_path / "l.tif"))
+
+
+def test_volume_writer_slab_by_slab_equals_whole_file_writers(tmp_path):
+    """io.VolumeWriter (the CLI files the result slab by slab while later slabs are still coming from the GPU) writes the
+    same bytes as write_mrc / write_tiff on the whole array; an MRC header needs the statistics up front."""
+    from flowdenoising_amd import io as fio
+    rng = np.random.default_rng(0)
+    for dt in (np.uint8, np.uint16, np.float32):
+        v = (rng.random((7, 9, 11)) * 200).astype(dt)
+        fio.write_tiff(str(tmp_path / "a.tif"), v)
+        w = fio.VolumeWriter(str(tmp_path / "b.tif"), v.shape, v.dtype)
+        for z0 in (0, 3, 5):
+            w.write_slab(v[z0:{0: 3, 3: 5, 5: 7}[z0]])
+        w.close()
+        assert (tmp_path / "a.tif").read_bytes() == (tmp_path / "b.tif").read_bytes()
+    v = rng.random((7, 9, 11)).astype(np.float32)
+    fio.write_mrc(str(tmp_path / "a.mrc"), v)
+    st = fio.volume_stats(v)
+    assert st["min"] == v.min() and st["max"] == v.max() and abs(st["mean"] - v.astype(np.float64).mean()) < 1e-15
+    w = fio.VolumeWriter(str(tmp_path / "b.mrc"), v.shape, np.float32, st)
+    w.write_slab(v[:4])
+    w.write_slab(v[4:])
+    w.close()
+    assert (tmp_path / "a.mrc").read_bytes() == (tmp_path / "b.mrc").read_bytes()
+    assert np.array_equal(fio.read_mrc(str(tmp_path / "b.mrc"), mmap=True), v)
+    with pytest.raises(ValueError, match="statistics"):
+        fio.VolumeWriter(str(tmp_path / "c.mrc"), v.shape, np.float32)
