@@ -6,8 +6,10 @@ winsize=5) on a synthetic 1024x1024x512 float32 volume (BASELINE.json configs[2]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one complete OF_filter of the volume (mean + three axis sweeps), input and output
-resident in HBM.  PyTorch is used for device memory, the synthetic generator and (N > 1)
-torch.distributed/RCCL; all arithmetic of the step runs in libflowdn.so.
+resident in HBM.  PyTorch is used for device memory and the synthetic generator only; all arithmetic of the
+step runs in libflowdn.so, and with N > 1 every exchange goes through libflowdn_rccl.so (ncclSend / ncclRecv over
+xGMI, include/flowdn_rccl.h) -- torch.distributed is not initialised (--engine python keeps the torch.distributed
+slab engine of flowdenoising_amd/distributed.py for comparison).
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
   "roofline":     the dominant kernel against the 8 TB/s HBM peak, priced on the bytes that kernel MUST move
@@ -49,8 +51,8 @@ def parse():
     ap.add_argument("--winsize", type=int, default=5, help="Farneback window (-w); configs[4] uses 15")
     ap.add_argument("--integer", choices=("", "seq", "par"), default="", help="time the integer-volume semantics instead (not the headline): "
                     "seq = float64 padded volume, par = integer images; N = 1 only")
-    ap.add_argument("--engine", choices=("python", "c"), default="python", help="N > 1: the slab engine above the C ABI (distributed.py) "
-                    "or fdn_filter_3d_sharded below it (transport through distributed.TorchComm)")
+    ap.add_argument("--engine", choices=("native", "python"), default="native", help="N > 1: fdn_filter_3d_sharded on the native transport "
+                    "(libflowdn_rccl.so: RCCL, or shared memory when ranks share a GPU), or the torch.distributed slab engine above the C ABI (distributed.py)")
     ap.add_argument("--path", type=int, default=0, help="fdn_set_option path: 0 auto, 1 staged, 2 per-iteration kernels")
     ap.add_argument("--cpu-targets", type=int, default=0, help="target slices of the CPU sample (0 = four per core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -266,9 +268,18 @@ def cpu_baseline(vol_t, shape, kernel, mean, n_targets, levels, winsize):
 
 
 def self_launch(a):
-    """`python bench.py --gpus N` from a bare shell (how the driver calls it): start the N ranks as a CHILD process
-    under torch.distributed.run -- before anything here imports torch or touches the GPU, and never by exec --,
-    relay rank 0's JSON line and return the child's exit code."""
+    """`python bench.py --gpus N` from a bare shell (how the driver calls it): start the N ranks as CHILD processes --
+    before anything here imports torch or touches the GPU, and never by exec --, relay rank 0's JSON line and return
+    the first non-zero exit code.  native engine: plain subprocess.Popen ranks that meet through libflowdn_rccl.so
+    (flowdenoising_amd/launch.py); python engine: torch.distributed.run, as that engine needs a process group."""
+    if a.engine == "native":
+        from flowdenoising_amd import launch
+
+        def relay(line):               # only the JSON line goes to stdout
+            out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+            out.write(line)
+            out.flush()
+        return launch.spawn([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], a.gpus, relay=relay)
     port = int(os.environ.get("MASTER_PORT", 0)) or 29500 + os.getpid() % 2000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -283,25 +294,85 @@ def self_launch(a):
     return proc.wait()
 
 
+def workload_names(shape, sig3, axes, levels, winsize):
+    """(metric, workload tag): BASELINE.json's own words for the configuration it quotes the metric on, and the index of
+    the BASELINE config this run is, if it is one of them."""
+    Z, Y, X = shape
+    cfg = None
+    table = {1: ((256, 512, 512), [2.0] * 3, "z", 0, 5), 2: ((512, 1024, 1024), [2.0] * 3, "zyx", 0, 5),
+             3: ((1024, 1024, 1024), [4.0] * 3, "zyx", 0, 5), 4: ((512, 2048, 2048), [2.0, 2.0, 4.0], "zyx", 3, 15),
+             0: ((64, 128, 128), [2.0] * 3, "zyx", 0, 5)}
+    for i, (sh, sg, ax, lv, ws) in table.items():
+        used = [sg[k] for k, c in enumerate("zyx") if c in ax]
+        mine = [sig3[k] for k, c in enumerate("zyx") if c in axes]
+        if tuple(shape) == sh and axes == ax and mine == used and levels == lv and winsize == ws:
+            cfg = i
+    sg = format(sig3[0], "g") if len(set(sig3)) == 1 else ",".join(format(v, "g") for v in sig3)
+    if cfg == 2:
+        metric = "Mvoxels/s denoised (sigma=2) on 1024x1024x512 float32"          # BASELINE.json "metric"
+    else:
+        metric = f"Mvoxels/s denoised (sigma={sg}) on {X}x{Y}x{Z} float32"
+    return metric, (f"BASELINE.json configs[{cfg}]" if cfg is not None else "not one of BASELINE.json's configs")
+
+
+def check_sharded(h, tr, dev, rank, world, shape, kernels, params, amplitude, slab_out, levels):
+    """After the timed region of an N > 1 run: every rank sends its output slab to rank 0 (native transport), which
+    regenerates the whole synthetic volume, filters it on its own GPU alone (fdn_filter_3d_dev), requires the gathered
+    sharded output to equal that single-GPU output bit for bit, and has the oracle recompute one target slice per pass
+    (check_output).  Returns the block on rank 0, None elsewhere."""
+    import torch
+    from flowdenoising_amd import distributed as fd, synth
+    Z, Y, X = shape
+    parts = fd.split(Z, world)
+    torch.cuda.synchronize()
+    if rank != 0:
+        tr.exchange([(slab_out.data_ptr(), slab_out.numel() * 4, 0, True)], 0)
+        torch.cuda.synchronize()
+        tr.barrier()                      # rank 0's single-GPU rerun and oracle check happen behind this barrier
+        return None
+    full = torch.empty(shape, dtype=torch.float32, device=dev)
+    full[parts[0][0]:parts[0][1]].copy_(slab_out)
+    tr.exchange([(full[z0:z1].data_ptr(), (z1 - z0) * Y * X * 4, r, False) for r, (z0, z1) in enumerate(parts) if r != 0], 0)
+    torch.cuda.synchronize()
+    vol = synth.make_volume(shape, seed=1234 + 3, amplitude=amplitude, xp=torch, device=dev)
+    single = torch.empty_like(vol)
+    mean = h.mean_dev(vol.data_ptr(), vol.numel())
+    h.filter_3d_dev(vol.data_ptr(), single.data_ptr(), shape, kernels, mean, params)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(full, single))
+    del full
+    res = check_output(h, vol, single, shape, kernels, params, mean)
+    res["sharded_output_equals_single_gpu_rerun"] = same
+    res["ok"] = bool(res["ok"] and same)
+    res["how"] = (f"the {world} ranks' output slabs gathered on rank 0 and compared with a single-GPU fdn_filter_3d_dev of the same "
+                  "synthetic volume (bit for bit); that single-GPU output then checked as at N = 1: " + res["how"])
+    tr.barrier()
+    return res
+
+
 def main():
     a = parse()
-    if a.gpus > 1 and "RANK" not in os.environ:
+    from flowdenoising_amd import launch
+    job = launch.job()
+    if a.gpus > 1 and job is None:
         sys.exit(self_launch(a))
     import torch
-    import torch.distributed as dist
     from flowdenoising_amd import _lib, synth
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:          # launched by torch.distributed.run with another rank count: the environment decides
+    rank, world, local_rank, rdv = job if job is not None else (0, 1, 0, None)
+    if world != a.gpus:          # started by torch.distributed.run with another rank count: the environment decides
         a.gpus = world
-    rehearsal = world > 1 and torch.cuda.device_count() < world
-    if rehearsal:            # fewer GPUs than ranks (a one-GPU box): the ranks share GPU 0 and exchange through the host
-        local_rank = 0       # over gloo -- exercises every line of the N > 1 path, its numbers mean nothing
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
+    ngpu = torch.cuda.device_count()
+    rehearsal = world > 1 and ngpu < world    # fewer GPUs than ranks (a one-GPU box): the ranks share GPUs and exchange through
+    tr = dist = None                          # host memory -- exercises every line of the N > 1 path, its numbers mean nothing
+    if world > 1 and a.engine == "native":
+        tr, device = launch.make_transport(rank, world, local_rank, rdv)      # RCCL, or shared memory when ranks share a GPU
+    else:
+        device = local_rank % max(ngpu, 1)
+    torch.cuda.set_device(device)
+    dev = torch.device("cuda", device)
+    if world > 1 and a.engine == "python":
+        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
@@ -314,19 +385,20 @@ def main():
     if len(sig3) != 3:
         sys.exit("--sigmas takes three values: Z,Y,X")
     ks3 = [_lib.gaussian_kernel(v) for v in sig3]
-    kernel = ks3[0]                  # the auxiliary lines (roofline byte model, sweep kernel, CPU sample) use the Z pass's taps
+    first_axis = next((i for i, c in enumerate("zyx") if c in a.axes), 0)
+    kernel = ks3[first_axis]         # the auxiliary lines (roofline byte model, sweep kernel, CPU sample) use the first pass's taps
     kernels = [ks3[i] if c in a.axes else None for i, c in enumerate("zyx")]
-    naxes = sum(k is not None for k in kernels)
     params = _lib.SweepParams(a.levels, a.winsize, 3, 5, 1.2, _lib.BORDER_MEAN_PAD, 1, 1)
     if a.integer == "par":
         params.border_mode, params.warp_mode, params.round_lo, params.round_hi = _lib.BORDER_WRAP, _lib.WARP_ROUND_INT, -32768.0, 32767.0
 
-    h = _lib.Handle(local_rank)
+    h = _lib.Handle(device)
     h.set_stream(torch.cuda.current_stream().cuda_stream)
     if a.path:
         h.set_option("path", a.path)
 
     eng = None
+    out_slab = None
     if world == 1:
         vol = synth.make_volume(shape, seed=1234 + 3, amplitude=a.amplitude, xp=torch, device=dev)
         out = torch.empty_like(vol)
@@ -341,28 +413,49 @@ def main():
             h.filter_3d_dev(vol.data_ptr(), out.data_ptr(), shape, kernels, mean, params)
             return mean
         parallelism = "1 GPU"
+        backend = "none"
     else:
         from flowdenoising_amd import distributed as fd
         plan = fd.SlabPlan(shape, world, rank)
         vol = synth.make_volume(shape, seed=1234 + 3, amplitude=a.amplitude, xp=torch, device=dev,
                                 z0=plan.z0, zlen=plan.zlen)
-        if a.engine == "c":
-            comm = fd.TorchComm(dist, dev)
+        out = None
+        if a.engine == "native":
             out_slab = torch.empty_like(vol)
 
             def step():
-                h.filter_3d_sharded(vol.data_ptr(), out_slab.data_ptr(), shape, kernels, params, comm)
+                h.filter_3d_sharded(vol.data_ptr(), out_slab.data_ptr(), shape, kernels, params, tr)
                 return None
+            backend = tr.describe().split(",")[0]
+            parallelism = (f"{world} Z-slabs, one exchange per pass (halos + repartition): fdn_filter_3d_sharded below the C ABI, "
+                           "point-to-point over RCCL (ncclSend / ncclRecv in one group per exchange, libflowdn_rccl.so)")
         else:
             eng = fd.SlabEngine(plan, h, dist)
 
             def step():
                 return eng.filter_3d(vol, kernels, params)
-        out = None
-        parallelism = f"{world} Z-slabs, one exchange per pass (halos + repartition, point-to-point over RCCL)" + (
-            "; engine below the C ABI (fdn_filter_3d_sharded)" if a.engine == "c" else "")
+            backend = dist.get_backend()
+            parallelism = f"{world} Z-slabs, one exchange per pass (halos + repartition), torch.distributed point-to-point ({backend}); slab engine above the C ABI"
         if rehearsal:
-            parallelism = f"REHEARSAL: {world} ranks sharing one GPU, exchanges staged through the host over gloo (not a measurement)"
+            parallelism = f"REHEARSAL: {world} ranks sharing {ngpu} GPU(s), exchanges staged through host memory (not a measurement)"
+
+    def barrier():
+        if tr is not None:
+            tr.barrier()
+        elif dist is not None:
+            dist.barrier()
+
+    def gather_f64(values):
+        """(world, n) array of every rank's float64 values."""
+        arr = np.asarray(values, dtype=np.float64)
+        if tr is not None:
+            return tr.allgather_array(arr)
+        if dist is not None:
+            t = torch.tensor(arr, dtype=torch.float64, device="cpu" if rehearsal else dev)
+            allr = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(allr, t)
+            return np.stack([r.cpu().numpy() for r in allr])
+        return arr[None]
 
     for _ in range(a.warmup):
         step()
@@ -370,52 +463,53 @@ def main():
     if not a.no_timers:
         h.enable_timers(True)
         h.timers(reset=True)
-        if eng is not None and hasattr(eng, "reset_phase_times"):
+        if eng is not None:
             eng.reset_phase_times()
-    if world > 1:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     mean = None
     for _ in range(a.steps):
         mean = step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = float(gather_f64([dt]).max())                    # the MAX over ranks
     timers = h.timers() if not a.no_timers else {}
     phases = None
-    if eng is not None and hasattr(eng, "phase_times") and not a.no_timers:
-        mine = eng.phase_times()          # ms per category on this rank, over the timed steps
+    if world > 1 and not a.no_timers:
+        if eng is not None:
+            mine = eng.phase_times()          # ms per category on this rank, over the timed steps
+        else:                                 # the library's own timer table (HIP events on the stream the work runs on)
+            kern = sum(timers[k][0] for k in ("polyexp", "update_matrices", "update_flow", "warp", "fused", "iter"))
+            mine = {"compute": kern, "pack_unpack_permute": timers["permute"][0], "exchange": timers["collective"][0], "mean": timers["mean"][0]}
         names = sorted(mine)
-        buf = torch.tensor([mine[n] for n in names], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        allr = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(allr, buf)
-        phases = {n: [round(float(r[i]) / a.steps, 2) for r in allr] for i, n in enumerate(names)}
+        allr = gather_f64([mine[n] for n in names])
+        phases = {n: [round(float(allr[r][i]) / a.steps, 2) for r in range(world)] for i, n in enumerate(names)}
 
+    nvox = Z * Y * X
+    res = None
     if rank == 0:
-        nvox = Z * Y * X
         ms_per_step = dt / a.steps * 1e3
         value = nvox / (dt / a.steps) / 1e6
+        metric, tag = workload_names(shape, sig3, a.axes, a.levels, a.winsize)
         res = {
-            "metric": "Mvoxels/s denoised (sigma=2) on 1024x1024x512 float32",
+            "metric": metric,
             "value": round(value, 3), "unit": "Mvoxels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
-            "backend": (dist.get_backend() if world > 1 else "none"),
+            "n_ranks_seen": world,
+            "backend": backend,
             "config": {"workload": f"{X}x{Y}x{Z} float32, sigma={a.sigmas or format(a.sigma, 'g')} (K={','.join(str(k.size) for k in ks3)}), levels={a.levels}, winsize={a.winsize}, "
-                                   f"OF along {a.axes.upper()}, mean-padded borders (BASELINE.json configs[2])",
+                                   f"OF along {a.axes.upper()}, mean-padded borders ({tag})",
                        "axes": a.axes, "parallelism": parallelism, "amplitude": a.amplitude,
                        "amplitude_note": "BASELINE.md's unit-range generator scaled by 100: OpenCV's absolute +1e-3 regulariser zeroes "
                                          "every flow on unit-range data.  Throughput depends on it a little: larger flows leave the "
                                          "kernel's LDS window more often"},
         }
+        if tr is not None:
+            res["transport"] = tr.describe()
         # whole path against the SURVEY 8(d) stage list (4832 B/voxel/axis at sigma=2): what an UNFUSED implementation
         # would have to move; above the HBM peak it measures traffic removed by fusion, not bandwidth
         path_bytes = sum(24 + (k.size - 1) * 300 + 8 for k in kernels if k is not None)
@@ -430,20 +524,30 @@ def main():
             res["phase_ms_per_step_per_rank"] = phases
         if a.integer:
             res["config"]["workload"] += f"; INTEGER-VOLUME SEMANTICS ({a.integer}) -- not the headline configuration"
-        if world == 1 and not a.no_check and not a.integer:
-            h.enable_timers(False)
-            res["checked"] = check_output(h, vol, out, shape, kernels, params, mean)
-            h.enable_timers(True)
-            if a.levels == 0:
-                res["sweep"] = sweep_line(h, vol, shape, kernel, params, mean)
+    if not a.no_check and not a.integer:
         h.enable_timers(False)
+        if world == 1:
+            res["checked"] = check_output(h, vol, out, shape, kernels, params, mean)
+            if a.levels == 0:
+                h.enable_timers(True)
+                res["sweep"] = sweep_line(h, vol, shape, kernel, params, mean)
+        elif tr is not None:
+            chk = check_sharded(h, tr, dev, rank, world, shape, kernels, params, a.amplitude, out_slab, a.levels)
+            if rank == 0:
+                res["checked"] = chk
+    h.enable_timers(False)
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(vol, shape, kernel, mean, a.cpu_targets, a.levels, a.winsize)
         print(json.dumps(res), flush=True)
-    h.enable_timers(False)
-    if world > 1:
-        dist.barrier()
+    barrier()
+    if dist is not None:
         dist.destroy_process_group()
+    if tr is not None:
+        tr.close()
+        if rank == 0 and "FDN_RDV" not in os.environ:      # a rendezvous directory derived under torch.distributed.run: ours to remove
+            import shutil
+            shutil.rmtree(rdv, ignore_errors=True)
 
 
 if __name__ == "__main__":

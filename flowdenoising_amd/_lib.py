@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libflowdn.so")
 USE_INITIAL_FLOW = 4
 BORDER_MEAN_PAD = 0
 BORDER_WRAP = 1
-TIMER_NAMES = ("polyexp", "update_matrices", "update_flow", "warp", "permute", "transfer", "fused", "iter", "collective")
+TIMER_NAMES = ("polyexp", "update_matrices", "update_flow", "warp", "permute", "transfer", "fused", "iter", "collective", "mean")
 
 
 class FlowdnError(RuntimeError):
@@ -43,13 +43,13 @@ DEPTHS = {np.dtype(np.float32): DEPTH_F32, np.dtype(np.float64): DEPTH_F64, np.d
 
 # every symbol include/flowdn.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "fdn_create", "fdn_destroy", "fdn_last_error", "fdn_set_stream", "fdn_reset_stream", "fdn_synchronize",
+    "fdn_create", "fdn_device_count", "fdn_destroy", "fdn_last_error", "fdn_set_stream", "fdn_reset_stream", "fdn_synchronize",
     "fdn_set_workspace_limit", "fdn_workspace_bytes", "fdn_mem_info", "fdn_set_option", "fdn_malloc", "fdn_free", "fdn_memcpy_h2d", "fdn_memcpy_d2h",
     "fdn_memcpy2d_h2d", "fdn_memcpy2d_d2h", "fdn_host_register", "fdn_host_unregister",
     "fdn_memset_f32", "fdn_gaussian_kernel", "fdn_farneback", "fdn_farneback_strided", "fdn_farneback_dev",
     "fdn_warp", "fdn_warp_strided", "fdn_warp_dev", "fdn_farneback_typed", "fdn_warp_typed",
     "fdn_filter_axis_dev", "fdn_filter_axis", "fdn_filter_3d_dev", "fdn_filter_3d",
-    "fdn_mean_host", "fdn_mean_dev", "fdn_np_chunk_sums_dev", "fdn_sum_dev", "fdn_stats_dev", "fdn_convert_dev", "fdn_truncate_dev", "fdn_reserve_3d", "fdn_filter_3d_sharded", "fdn_sweep_stack_dev", "fdn_permute_dev",
+    "fdn_mean_host", "fdn_mean_dev", "fdn_np_chunk_sums_dev", "fdn_sum_dev", "fdn_stats_dev", "fdn_stats_slices_dev", "fdn_convert_dev", "fdn_truncate_dev", "fdn_reserve_3d", "fdn_filter_3d_sharded", "fdn_sweep_stack_dev", "fdn_permute_dev",
     "fdn_enable_timers", "fdn_get_timers", "fdn_add_timer", "fdn_version",
 ]
 
@@ -69,6 +69,13 @@ class FdnComm(ctypes.Structure):
 
 
 _lib = None
+_rccl = None
+RCCL_LIB_PATH = os.path.join(_HERE, "libflowdn_rccl.so")
+TRANSPORT_RCCL, TRANSPORT_SHM, TRANSPORT_NULL = 0, 1, 2
+# every symbol include/flowdn_rccl.h declares
+RCCL_EXPORTS = ["fdn_transport_create", "fdn_transport_destroy", "fdn_transport_last_error", "fdn_transport_describe",
+                "fdn_transport_comm", "fdn_transport_exchange", "fdn_transport_allgather_host", "fdn_transport_barrier"]
+_torch_runtime = None      # directory of the torch-bundled ROCm libraries when libflowdn.so was bound to them
 
 
 def _share_hip_runtime_with_torch():
@@ -79,16 +86,21 @@ def _share_hip_runtime_with_torch():
     torch itself is NOT imported here."""
     import importlib.util
     import sys
-    if "torch" in sys.modules:
-        return
+    global _torch_runtime
+    if os.environ.get("FDN_SYSTEM_ROCM") == "1" and "torch" not in sys.modules:
+        return      # a process that will never import torch (the ranks of `flowdenoising.py --gpus N`): /opt/rocm's runtime
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
         spec = None
     if spec is None or not spec.submodule_search_locations:
         return
-    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    cand = os.path.join(libdir, "libamdhip64.so")
     if os.path.exists(cand):
+        _torch_runtime = libdir
+        if "torch" in sys.modules:
+            return
         try:
             ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
         except OSError:
@@ -114,6 +126,99 @@ def load():
             fn.restype = ctypes.c_int
     _lib = lib
     return lib
+
+
+def load_rccl():
+    """Load libflowdn_rccl.so (include/flowdn_rccl.h: the native transports of fdn_filter_3d_sharded).  RCCL has to sit on
+    the HIP runtime libflowdn.so is bound to: where that is the torch-bundled one (a process that imports torch), the
+    torch-bundled librccl -- same soname -- is loaded first and the dynamic linker resolves our dependency to it."""
+    global _rccl
+    if _rccl is not None:
+        return _rccl
+    load()
+    if not os.path.exists(RCCL_LIB_PATH):
+        raise FlowdnError(f"{RCCL_LIB_PATH} not found: build it with `make -C flowdenoising_amd/csrc`")
+    if _torch_runtime is not None:
+        cand = os.path.join(_torch_runtime, "librccl.so")
+        if os.path.exists(cand):
+            try:
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
+    lib = ctypes.CDLL(RCCL_LIB_PATH)
+    for name in RCCL_EXPORTS:
+        getattr(lib, name).restype = ctypes.c_int
+    lib.fdn_transport_last_error.restype = ctypes.c_char_p
+    lib.fdn_transport_describe.restype = ctypes.c_char_p
+    lib.fdn_transport_describe.argtypes = [ctypes.c_void_p]
+    lib.fdn_transport_comm.restype = ctypes.c_void_p
+    lib.fdn_transport_comm.argtypes = [ctypes.c_void_p]
+    _rccl = lib
+    return lib
+
+
+class Transport:
+    """One fdn_transport (include/flowdn_rccl.h): `kind` "rccl" (one GPU per rank, ncclSend / ncclRecv over xGMI), "shm"
+    (ranks sharing a GPU, staged through shared memory: a rehearsal) or "null" (moves nothing: per-rank overhead
+    emulation).  Creation is collective over the ranks of the job; `rendezvous` is the directory the launcher made."""
+
+    KINDS = {"rccl": TRANSPORT_RCCL, "shm": TRANSPORT_SHM, "null": TRANSPORT_NULL}
+
+    def __init__(self, kind, rank, world, device=0, rendezvous=None):
+        self._lib = load_rccl()
+        self._t = ctypes.c_void_p()
+        self.kind, self.rank, self.world, self.device = kind, int(rank), int(world), int(device)
+        rc = self._lib.fdn_transport_create(ctypes.c_int(self.KINDS[kind]), ctypes.c_int(self.rank), ctypes.c_int(self.world),
+                                            ctypes.c_int(self.device), (rendezvous or "").encode(), ctypes.byref(self._t))
+        self._check(rc)
+
+    def _check(self, rc):
+        if rc < 0:
+            raise FlowdnError(self._lib.fdn_transport_last_error().decode("utf-8", "replace"))
+
+    def describe(self):
+        return self._lib.fdn_transport_describe(self._t).decode()
+
+    def comm_ptr(self):
+        """const fdn_comm* for fdn_filter_3d_sharded."""
+        p = self._lib.fdn_transport_comm(self._t)
+        if not p:
+            self._check(-1)
+        return ctypes.c_void_p(p)
+
+    def exchange(self, msgs, stream=None):
+        """msgs = [(device pointer, nbytes, peer, is_send)]: one batched group on `stream` (a hipStream_t as an int)."""
+        arr = (FdnMsg * max(len(msgs), 1))()
+        for i, (p, n, peer, snd) in enumerate(msgs):
+            arr[i] = FdnMsg(ctypes.c_void_p(int(p)), int(n), int(peer), int(bool(snd)))
+        self._check(self._lib.fdn_transport_exchange(self._t, ctypes.c_int(len(msgs)), arr, ctypes.c_void_p(int(stream or 0))))
+
+    def allgather_host(self, send):
+        """bytes of every rank, concatenated in rank order."""
+        send = bytes(send)
+        out = ctypes.create_string_buffer(len(send) * self.world)
+        self._check(self._lib.fdn_transport_allgather_host(self._t, send, out, ctypes.c_size_t(len(send))))
+        return out.raw
+
+    def allgather_array(self, arr):
+        """(world,) + arr.shape array: every rank's `arr` (same shape and dtype on all ranks)."""
+        arr = np.ascontiguousarray(arr)
+        raw = self.allgather_host(arr.tobytes())
+        return np.frombuffer(raw, dtype=arr.dtype).reshape((self.world,) + arr.shape).copy()
+
+    def barrier(self):
+        self._check(self._lib.fdn_transport_barrier(self._t))
+
+    def close(self):
+        if self._t:
+            self._lib.fdn_transport_destroy(self._t)
+            self._t = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def check(rc):
@@ -143,6 +248,30 @@ def mean_host(vol):
     m = ctypes.c_float()
     check(lib.fdn_mean_host(_ptr(vol), ctypes.c_size_t(vol.size), ctypes.byref(m)))
     return np.float32(m.value)
+
+
+def device_count():
+    """HIP devices visible to this process (fdn_device_count)."""
+    n = ctypes.c_int()
+    check(load().fdn_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def combine_slice_stats(first, count, second=None):
+    """Volume statistics from per-slice ones, slices added in order (python floats: IEEE doubles, one fixed order):
+    first = fdn_stats_slices_dev(centre 0) rows {min, max, sum, .}; second = the rows taken with centre = mean."""
+    mn, mx, tot = first[0][0], first[0][1], 0.0
+    for a, b, s, _ in first:
+        mn = a if (a < mn or a != a) else mn
+        mx = b if (b > mx or b != b) else mx
+        tot += float(s)
+    out = {"min": float(mn), "max": float(mx), "mean": tot / float(count), "std": float("nan")}
+    if second is not None:
+        sq = 0.0
+        for row in second:
+            sq += float(row[3])
+        out["std"] = float(np.sqrt(sq / float(count)))
+    return out
 
 
 class Handle:
@@ -192,7 +321,7 @@ class Handle:
         return f.value, t.value
 
     def set_option(self, name, value):
-        """fdn_set_option: "strict_order", "path", "fused_occ", "lds_pad" (see include/flowdn.h)."""
+        """fdn_set_option: "strict_order", "path", "fused_occ", "lds_pad", "shard_loopback" (see include/flowdn.h)."""
         check(self._lib.fdn_set_option(self._h, ctypes.c_char_p(name.encode()), ctypes.c_long(int(value))))
 
     def malloc(self, nbytes):
@@ -392,9 +521,14 @@ class Handle:
     def filter_3d_sharded(self, d_slab_in, d_slab_out, shape, kernels, params, comm):
         """fdn_filter_3d_sharded: this rank's Z-slab in, filtered Z-slab out, the transport behind `comm`:
         an object with .rank, .world, .exchange(msgs, stream) -- msgs = [(device pointer, nbytes, peer, is_send)] --
-        and .allgather_host(send: bytes) -> bytes of all ranks in rank order (distributed.TorchComm is one)."""
+        and .allgather_host(send: bytes) -> bytes of all ranks in rank order (distributed.TorchComm is one) -- or a
+        Transport (RCCL / shared memory / null, libflowdn_rccl.so), whose C callbacks the library then calls directly."""
         Z, Y, X = shape
         ptrs, Ks, keep = self._kernels(kernels)
+        if isinstance(comm, Transport):         # a native transport (libflowdn_rccl.so): no Python in the data path
+            check(self._lib.fdn_filter_3d_sharded(self._h, ctypes.c_void_p(d_slab_in), ctypes.c_void_p(d_slab_out), ctypes.c_int(Z),
+                                                  ctypes.c_int(Y), ctypes.c_int(X), ptrs, Ks, ctypes.byref(params), comm.comm_ptr()))
+            return
         errors = []
 
         def _exchange(ctx, n, msgs, stream):
@@ -453,6 +587,22 @@ class Handle:
         out = (ctypes.c_double * 4)()
         check(self._lib.fdn_stats_dev(self._h, ctypes.c_void_p(d_in), ctypes.c_size_t(int(count)), out))
         return {"min": out[0], "max": out[1], "mean": out[2], "std": out[3]}
+
+    def stats_volume(self, d_in, shape):
+        """The same four numbers from per-slice reductions added up in slice order (fdn_stats_slices_dev): independent of
+        how a volume is cut into Z-slabs, so a multi-GPU run writes the single-GPU header bit for bit."""
+        n = int(shape[0])
+        per = int(np.prod(shape[1:]))
+        first = self.stats_slices_dev(d_in, n, per, 0.0)
+        mean = combine_slice_stats(first, n * per)["mean"]
+        return combine_slice_stats(first, n * per, self.stats_slices_dev(d_in, n, per, mean))
+
+    def stats_slices_dev(self, d_in, nslices, slice_elems, centre):
+        """(nslices, 4) float64: min, max, sum, sum of squared deviations from `centre` of every slice."""
+        out = np.empty((int(nslices), 4), dtype=np.float64)
+        check(self._lib.fdn_stats_slices_dev(self._h, ctypes.c_void_p(d_in), ctypes.c_int(int(nslices)), ctypes.c_size_t(int(slice_elems)),
+                                             ctypes.c_double(float(centre)), ctypes.c_void_p(out.ctypes.data)))
+        return out
 
     def convert_dev(self, d_src, dtype, d_dst, count):
         """d_dst (float32) = float32(d_src) for a device array of an 8- or 16-bit integer dtype."""

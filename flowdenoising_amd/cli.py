@@ -11,8 +11,8 @@ behaviour: levels = 3 by default, wrap-around volume ends (par:312), float32 TIF
 (par:548).  (par's loss of its X pass, par:290 + par:520, is not reproduced: the full Z->Y->X
 result is written, as src/flowdenoising_GPU.py:460 does.)
 
-New options: --device N (GPU index), --gpus N (shard over N GPUs of this node; re-launches itself
-under torch.distributed.run), --chunk_slices N (out-of-core mode for volumes larger than the GPU's
+New options: --device N (GPU index), --gpus N (shard over N GPUs of this node: N rank processes started with
+subprocess.Popen, exchanges through libflowdn_rccl.so -- RCCL over xGMI; PyTorch is not involved), --chunk_slices N (out-of-core mode for volumes larger than the GPU's
 memory: the volume stays on the host, N slices of a pass at a time on the GPU; -1 = as many as fit),
 --strict_order (OpenCV's own f64 summation order in the box filter; slow, for verification).
 """
@@ -93,7 +93,7 @@ def _run_single(args, vol, kernels, l, w, device, stats, as_float32, timing=None
         if wait_for is not None:
             wait_for()
         if as_float32:
-            vol = vol.astype(np.float32)            # seq:517
+            vol = np.asarray(vol, dtype=np.float32)     # seq:517 (main() has usually converted a TIFF stack already: no second copy)
         return filter_streamed(vol, kernels, l, w, None if args.chunk_slices < 0 else args.chunk_slices,
                                use_of=not args.no_OF, border_mode=border, chained=not args.recompute_flow, device=device)
     # mean = vol.mean() (seq:420) and the statistics the reference logs / mrcfile writes: taken on the GPU
@@ -125,55 +125,101 @@ def _reserve(args, shape, dtype, Ks, l, w):
         logging.debug(f"reserve: {e}")
 
 
-def _run_sharded(args, shape, kernels, l, w, stats=None):
-    """Called under torch.distributed.run (one rank per GPU).  Every rank reads ITS OWN Z-slab of the input file;
-    the global mean (seq:420) is assembled from the ranks' chunk sums (numpy's float32 value, bit for bit); the
-    filtered slabs are sent to rank 0 only, which writes the output."""
-    import torch
-    import torch.distributed as dist
-    from . import _lib
+def _gather_slice_rows(tr, rows, parts):
+    """Per-slice rows (zlen, 4) of every rank -> (Z, 4) in slice order (slabs differ in length: padded for the all-gather)."""
+    m = max(e - s_ for s_, e in parts)
+    pad = np.zeros((m, 4), dtype=np.float64)
+    pad[:rows.shape[0]] = rows
+    got = tr.allgather_array(pad)
+    return np.concatenate([got[r, :e - s_] for r, (s_, e) in enumerate(parts)])
+
+
+def _run_sharded(args, shape, kernels, l, w, stats, job, wall):
+    """One rank of `--gpus N` (flowdenoising_amd/launch.py started it; no PyTorch anywhere): reads ITS OWN Z-slab of the
+    input file, runs fdn_filter_3d_sharded on the native transport (RCCL over xGMI with one GPU per rank, the shared-memory
+    rehearsal transport when ranks share a GPU), and writes its slab of the result into the output file at the byte offset
+    those slices have there -- no rank ever holds the whole volume.  The header statistics (seq:562-564) and seq:566-571's
+    uint8 / uint16 decision come from per-slice reductions all-gathered in slice order: the file is the single-GPU run's,
+    byte for byte.  The partition is src/flowdenoising.py:181-206's: near-equal contiguous chunks of target slices."""
+    from . import _lib, launch
     from . import io as fio
-    from .distributed import SlabEngine, SlabPlan
-    from .operators import _params, integer_semantics
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    local = int(os.environ.get("LOCAL_RANK", rank))
-    if torch.cuda.device_count() >= world:          # one GPU per rank, exchanges over RCCL / xGMI
-        torch.cuda.set_device(local)
-        dev = torch.device("cuda", local)
-        dist.init_process_group("nccl", device_id=dev)
-    else:                                           # fewer GPUs than ranks (a rehearsal box): share GPU 0, exchanges staged over gloo
-        local = 0
-        torch.cuda.set_device(0)
-        dev = torch.device("cuda", 0)
-        dist.init_process_group("gloo")
-        logging.warning(f"--gpus {world} on a node with {torch.cuda.device_count()} GPU(s): the ranks share GPU 0")
-    plan = SlabPlan(shape, world, rank)
-    raw = fio.read_slab(args.input, plan.z0, plan.z0 + plan.zlen)
-    if not fio.is_mrc_input(args.input):
-        raw = raw.astype(np.float32)                # seq:517: only an MRC keeps an integer dtype
+    from .distributed import split
+    from .operators import _download_into, _params, integer_semantics
+    rank, world, local, rdv = job
+    tr, device = launch.make_transport(rank, world, local, rdv)
+    logging.info(f"rank {rank}: {tr.describe()}")
+    h = _lib.Handle(device)
+    Z, Y, X = shape
+    parts = split(Z, world)
+    z0, z1 = parts[rank]
+    t0 = time.perf_counter()
+    raw = fio.read_slab(args.input, z0, z1)
+    as_float32 = not fio.is_mrc_input(args.input)          # seq:517: only an MRC keeps an integer dtype
     border = _lib.BORDER_WRAP if args.compat == "par" else _lib.BORDER_MEAN_PAD
-    params = integer_semantics(raw, _params(l, w, use_of=not args.no_OF, border_mode=border, chained=not args.recompute_flow))
-    mean = None
-    if params.warp_mode == _lib.WARP_F64_PADDED:    # an integer MRC (seq:513): numpy's float64 mean of the WHOLE volume = exact integer sum / count
-        tot = torch.tensor([int(raw.sum(dtype=np.int64))], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tot)
-        params.pad64 = float(int(tot.item())) / float(shape[0] * shape[1] * shape[2])
-        mean = np.float32(params.pad64)
-    mine = np.ascontiguousarray(raw, dtype=np.float32)   # seq:517
-    slab = torch.from_numpy(mine).to(dev)
-    h = _lib.Handle(local)
-    h.set_stream(torch.cuda.current_stream().cuda_stream)
-    eng = SlabEngine(plan, h, dist)
-    out = eng.filter_3d(slab, kernels, params, mean=mean)
-    full = eng.gather_z_slabs(out, 0)               # slabs may differ in length: point-to-point into their place, rank 0 only
-    if rank == 0 and stats is not None:             # what the reference logs about the result and mrcfile puts into the header
-        torch.cuda.synchronize()
-        stats["out"] = h.stats_dev(full.data_ptr(), full.numel())
-    res = full.cpu().numpy() if rank == 0 else None
-    logging.info(f"rank {rank} phases (ms): " + ", ".join(f"{k} {v:.1f}" for k, v in eng.phase_times().items()))
-    dist.barrier()
-    dist.destroy_process_group()
-    return res
+    params = _params(l, w, use_of=not args.no_OF, border_mode=border, chained=not args.recompute_flow)
+    if not as_float32:
+        params = integer_semantics(raw, params, mean_on_device=True)
+    raw_int = raw.dtype.kind in "iu" and raw.dtype.itemsize <= 2 and raw.dtype.isnative
+    src = np.ascontiguousarray(raw) if raw_int else np.ascontiguousarray(raw, dtype=np.float32)
+    n = src.size
+    d_in = h.malloc(n * 4)
+    d_out = h.malloc(n * 4)
+    try:
+        h.h2d(d_out if raw_int else d_in, src)             # raw integers into the (larger) output buffer first
+        if raw_int:
+            h.convert_dev(d_out, src.dtype, d_in, n)
+        h.synchronize()
+        wall["h2d"] = time.perf_counter() - t0
+        verbose = logging.getLogger().isEnabledFor(logging.INFO)
+        if verbose or params.pad64 != params.pad64:
+            rows = _gather_slice_rows(tr, h.stats_slices_dev(d_in, z1 - z0, Y * X, 0.0), parts)
+            st_in = _lib.combine_slice_stats(rows, Z * Y * X)
+            if stats is not None:
+                stats["in"] = st_in
+            if params.pad64 != params.pad64:               # an integer MRC's float64 mean (seq:420): exact sums of integers
+                params.pad64 = st_in["mean"]
+        t0 = time.perf_counter()
+        h.filter_3d_sharded(d_in, d_out, shape, kernels, params, tr)
+        h.synchronize()
+        wall["compute"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        mrc_out = fio.is_mrc_output(args.output)
+        downcast = not mrc_out and args.compat != "par"    # seq:566-571's uint8 / uint16 TIFF, cast on the GPU
+        first = _gather_slice_rows(tr, h.stats_slices_dev(d_out, z1 - z0, Y * X, 0.0), parts)
+        st_out = _lib.combine_slice_stats(first, Z * Y * X)
+        if mrc_out or verbose:
+            second = _gather_slice_rows(tr, h.stats_slices_dev(d_out, z1 - z0, Y * X, st_out["mean"]), parts)
+            st_out = _lib.combine_slice_stats(first, Z * Y * X, second)
+        if stats is not None:
+            stats["out"] = st_out
+        d_res, dtype = d_out, np.dtype(np.float32)
+        if downcast:
+            dtype = np.dtype(np.uint8 if st_out["max"] < 256 else np.uint16)
+            h.truncate_dev(d_out, dtype, d_in, n)          # the input's device copy is no longer needed
+            d_res = d_in
+        out = np.empty((z1 - z0, Y, X), dtype=dtype)
+        if rank == 0:                                      # the file and its header exist before anybody else opens it
+            writer = fio.VolumeWriter(args.output, shape, dtype, st_out, z0=0, create=True)
+        tr.barrier()
+        if rank != 0:
+            writer = fio.VolumeWriter(args.output, shape, dtype, st_out, z0=z0, create=False)
+        pin = out.nbytes >= (8 << 20) and h.host_register(out)
+        try:
+            _download_into(h, out, d_res, writer)
+        finally:
+            if pin:
+                h.host_unregister(out)
+        tr.barrier()                                       # every slab is in the file
+        wall["d2h_write"] = time.perf_counter() - t0
+        if stats is not None:
+            stats["streamed"] = True
+            stats["dtype"] = dtype
+    finally:
+        h.free(d_out)
+        h.free(d_in)
+        tr.close()
+        h.close()
+    return None
 
 
 def main(argv=None):
@@ -197,17 +243,22 @@ def main(argv=None):
     if args.verbosity in (1, 2):
         logging.info(f"Verbosity level = {args.verbosity}")
 
-    sharded = "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1
+    from . import launch
+    job = launch.job() if args.gpus > 1 else None
+    sharded = job is not None
     if args.gpus > 1 and (args.chunk_slices or args.device):
         parser.error("--gpus shards the volume over GPUs 0..N-1 and keeps every slab resident: "
                      "it cannot be combined with --chunk_slices or --device")
     if args.gpus > 1 and not sharded:
-        import subprocess
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000),
-               os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flowdenoising.py")]
-        return subprocess.call(cmd + (sys.argv[1:] if argv is None else list(argv)))
-    rank = int(os.environ.get("RANK", "0")) if sharded else 0
+        # the parent: N rank processes of this same command, started with plain subprocess.Popen before anything here has
+        # touched a GPU (never an exec); they meet through the native transport (include/flowdn_rccl.h) -- no PyTorch
+        script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flowdenoising.py")
+        env = dict(os.environ)
+        env.setdefault("FDN_SYSTEM_ROCM", "1")     # the ranks never import torch: /opt/rocm's HIP runtime and RCCL
+        return launch.spawn([sys.executable, script] + (sys.argv[1:] if argv is None else list(argv)), args.gpus, env=env)
+    if sharded and job[1] != args.gpus:
+        parser.error(f"--gpus {args.gpus} inside a job of {job[1]} ranks")
+    rank = job[0] if sharded else 0
 
     sigma = [float(i) for i in args.sigma]
     logging.info(f"sigma={tuple(sigma)}")
@@ -261,21 +312,22 @@ def main(argv=None):
     state["stage"] = "filtering"
     t0 = time.perf_counter()
     if sharded:
-        filtered = _run_sharded(args, shape, kernels, l, w, stats)
+        filtered = _run_sharded(args, shape, kernels, l, w, stats, job, wall)
     else:
         filtered = _run_single(args, vol, kernels, l, w, args.device, stats, as_float32, timing=wall,
                                wait_for=prep.join if prep is not None else None)
     wall["filter"] = time.perf_counter() - t0
     logging.info(f"Volume filtered in {wall['filter']} seconds")
     if rank != 0:
+        _assert_no_torch()
         return 0
     if "in" in stats:            # seq:529-532, from the device copy
         logging.info(f"{args.input} max = {stats['in']['max']}")
         logging.info(f"{args.input} min = {stats['in']['min']}")
         logging.info(f"Input vol average = {stats['in']['mean']}")
 
-    logging.info(f"shape of the denoised volume (Z, Y, X) = {filtered.shape}")
-    logging.info(f"{args.output} type = {filtered.dtype}")
+    logging.info(f"shape of the denoised volume (Z, Y, X) = {filtered.shape if filtered is not None else tuple(shape)}")
+    logging.info(f"{args.output} type = {filtered.dtype if filtered is not None else stats.get('dtype')}")
     if "out" in stats:           # seq:547-550
         logging.info(f"{args.output} max = {stats['out']['max']}")
         logging.info(f"{args.output} min = {stats['out']['min']}")
@@ -294,7 +346,15 @@ def main(argv=None):
         import json
         with open(os.environ["FDN_CLI_TIMING"], "w") as f:
             json.dump(wall, f)
+    _assert_no_torch()
     return 0
+
+
+def _assert_no_torch():
+    """FDN_ASSERT_NO_TORCH=1 (tests): the drop-in -- single GPU or `--gpus N` -- must finish without PyTorch ever having
+    been imported into the process (BASELINE north_star: "PyTorch-ROCm is not needed here")."""
+    if os.environ.get("FDN_ASSERT_NO_TORCH") == "1" and "torch" in sys.modules:
+        raise AssertionError("torch was imported by the product path")
 
 
 if __name__ == "__main__":

@@ -149,6 +149,7 @@ struct DevBuf {
 
 struct fdn_ctx {
     bool reserve_only = false;   // fdn_reserve_3d: size and allocate every buffer of a call, launch nothing
+    size_t reserve_extern = 0;   // ... leaving this much free: the caller's own input / output volumes, not allocated yet
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -658,6 +659,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
         // rebuilt per batch as under a limit instead of failing in hipMalloc.
         size_t fre = 0, tot = 0;
         FDN_HIP(hipMemGetInfo(&fre, &tot));
+        if (h->reserve_only) fre -= std::min(fre, h->reserve_extern);     // the caller's two whole-volume buffers come after the reservation
         auto grow = [](const DevBuf& b, size_t want) { return want > b.cap ? want : (size_t)0; };     // bytes ensure() will newly claim (the old block is freed first)
         const size_t r_all = (size_t)(S + 2 * r) * 5 * HW * sizeof(float);
         const size_t pyr_all = pyramid ? (size_t)(S + 2 * r) * HW * 7 + std::min<size_t>((size_t)1 << 30, HW * 12 * (size_t)(S + 2 * r)) : 0;
@@ -997,6 +999,9 @@ static int shard_exchange(fdn_ctx* h, const ShardPlan& pl, const fdn_comm* comm,
                           float* stack, int Hs, int Ws)
 {
     const int me = pl.rank, world = pl.world;
+    // loopback (a test switch, fdn_set_option "shard_loopback"): the block this rank keeps goes through the transport as a
+    // send to self inside the group, so that one rank on one GPU issues exactly the calls of an N > 1 run
+    const bool loop = h->tn.shard_loopback != 0;
     const int* oa = ORIENT[A];
     const int* ob = ORIENT[B];
     const Range mineA = pl.part(A, me);
@@ -1010,7 +1015,7 @@ static int shard_exchange(fdn_ctx* h, const ShardPlan& pl, const fdn_comm* comm,
         pl.blocks(A, B, r, wrap, me, j, sends[j]);
         pl.blocks(A, B, r, wrap, j, me, recvs[j]);
         for (auto& b : sends[j]) n_send += ShardPlan::numel(b);
-        if (j != me) for (auto& b : recvs[j]) n_recv += ShardPlan::numel(b);
+        if (j != me || loop) for (auto& b : recvs[j]) n_recv += ShardPlan::numel(b);
     }
     if (ensure(h, h->sh_send, std::max<size_t>(n_send, 1) * sizeof(float)) || ensure(h, h->sh_recv, std::max<size_t>(n_recv, 1) * sizeof(float))) return -1;
     float* sendbuf = (float*)h->sh_send.p;
@@ -1037,7 +1042,7 @@ static int shard_exchange(fdn_ctx* h, const ShardPlan& pl, const fdn_comm* comm,
         std::vector<fdn_msg> msgs;
         for (int i = 0; i < world; i++) {
             recv_off[i] = off;
-            if (i == me) continue;
+            if (i == me && !loop) continue;
             size_t n = 0;
             for (auto& b : recvs[i]) n += ShardPlan::numel(b);
             if (n) msgs.push_back({recvbuf + off, n * sizeof(float), i, 0});
@@ -1045,8 +1050,8 @@ static int shard_exchange(fdn_ctx* h, const ShardPlan& pl, const fdn_comm* comm,
         }
         recv_off[world] = off;
         for (int j = 0; j < world; j++)
-            if (j != me && send_off[j + 1] > send_off[j]) msgs.push_back({sendbuf + send_off[j], (send_off[j + 1] - send_off[j]) * sizeof(float), j, 1});
-        if (world > 1) {
+            if ((j != me || loop) && send_off[j + 1] > send_off[j]) msgs.push_back({sendbuf + send_off[j], (send_off[j + 1] - send_off[j]) * sizeof(float), j, 1});
+        if (world > 1 || loop) {
             ScopedTimer t(h, FDN_TIMER_COLLECTIVE);
             if (comm->exchange(comm->ctx, (int)msgs.size(), msgs.data(), (void*)h->stream)) return fail("fdn_comm.exchange failed (pass along axis %d)", B);
         }
@@ -1054,7 +1059,7 @@ static int shard_exchange(fdn_ctx* h, const ShardPlan& pl, const fdn_comm* comm,
     {   // 3. unpack into the stack (the block this rank keeps comes straight from its send buffer)
         ScopedTimer t(h, FDN_TIMER_PERMUTE);
         for (int i = 0; i < world; i++) {
-            const float* buf = i == me ? sendbuf + send_off[me] : recvbuf + recv_off[i];
+            const float* buf = (i == me && !loop) ? sendbuf + send_off[me] : recvbuf + recv_off[i];
             size_t off = 0;
             for (auto& b : recvs[i]) {
                 const int n0 = b.rng[ob[0]].hi - b.rng[ob[0]].lo, n1 = b.rng[ob[1]].hi - b.rng[ob[1]].lo, n2 = b.rng[ob[2]].hi - b.rng[ob[2]].lo;
@@ -1081,7 +1086,7 @@ static int shard_mean(fdn_ctx* h, const ShardPlan& pl, const fdn_comm* comm, con
     starts[world] = ntot;
     for (int k = 0; k < world; k++) minlen = std::min(minlen, starts[k + 1] - starts[k]);
     const size_t mylen = starts[me + 1] - starts[me];
-    if (world == 1) return fdn_mean_dev(h, slab, ntot, mean_out);
+    if (world == 1 && !h->tn.shard_loopback) return fdn_mean_dev(h, slab, ntot, mean_out);
     if (minlen < 8192) {        // tiny volume: a chunk may span several slabs; gather the whole thing (it is small)
         size_t m = 0;
         for (int k = 0; k < world; k++) m = std::max(m, starts[k + 1] - starts[k]);
@@ -1144,7 +1149,10 @@ static int filter_3d_sharded(fdn_ctx* h, const float* slab_in, float* slab_out, 
     const bool wrap = p->border_mode == FDN_BORDER_WRAP;
     float mean = 0.f;
     if (p->warp_mode == FDN_WARP_F64_PADDED) mean = (float)p->pad64;
-    else if (!wrap && shard_mean(h, pl, comm, slab_in, &mean)) return -1;
+    else if (!wrap) {
+        ScopedTimer t(h, FDN_TIMER_MEAN);
+        if (shard_mean(h, pl, comm, slab_in, &mean)) return -1;
+    }
     const float* cur = slab_in;
     int cur_axis = 0, flip = 0;
     for (int axis = 0; axis < 3; axis++) {
@@ -1284,7 +1292,8 @@ FDN_API int fdn_set_option(fdn_handle h, const char* name, long value)
     else if (!strcmp(name, "path")) { if (value < 0 || value > 2) return fail("path must be 0 (auto), 1 (staged) or 2 (per-iteration kernels)"); h->tn.path = (int)value; }
     else if (!strcmp(name, "fused_occ")) { if (value && (value < 3 || value > 5) && value != 8) return fail("fused_occ must be 0, 3, 4, 5 or 8"); h->tn.fused_occ = (int)value; }
     else if (!strcmp(name, "lds_pad")) { if (value < 0 || value > 160 * 1024) return fail("lds_pad out of range"); h->tn.lds_pad = (unsigned)value; }
-    else return fail("unknown option '%s' (strict_order, path, fused_occ, lds_pad)", name);
+    else if (!strcmp(name, "shard_loopback")) h->tn.shard_loopback = value != 0;
+    else return fail("unknown option '%s' (strict_order, path, fused_occ, lds_pad, shard_loopback)", name);
     return 0;
 }
 FDN_API int fdn_malloc(fdn_handle h, size_t bytes, void** dptr)
@@ -1754,9 +1763,14 @@ FDN_API int fdn_reserve_3d(fdn_handle h, int Z, int Y, int X, const int K[3], co
     const double* kern[3] = {K[0] > 0 ? &one : nullptr, K[1] > 0 ? &one : nullptr, K[2] > 0 ? &one : nullptr};   // never read
     float* const fake_in = (float*)(uintptr_t)16;    // never dereferenced: the sizing logic only compares them
     float* const fake_out = (float*)(uintptr_t)32;
+    // The flow batch of a pass is sized from the free device memory (sweep_stack), and a reservation runs BEFORE the caller
+    // allocates its own input and output volumes (the CLI reserves while it reads the file): without their 8 bytes per voxel
+    // set aside here a volume whose flows do not all fit would get a batch that leaves no room for them.
     h->reserve_only = true;
+    h->reserve_extern = (size_t)2 * Z * Y * X * sizeof(float);
     const int rc = filter_3d_dev(h, fake_in, fake_out, Z, Y, X, kern, K, 0.f, p);
     h->reserve_only = false;
+    h->reserve_extern = 0;
     return rc;
 }
 
@@ -1776,12 +1790,53 @@ FDN_API int fdn_stats_dev(fdn_handle h, const float* d_in, size_t count, double*
         FDN_HIP(hipStreamSynchronize(h->stream));
         mn = host[0]; mx = host[1]; sum = 0; sq = 0;
         for (int i = 0; i < nb; i++) {
-            mn = std::min(mn, host[4 * i]); mx = std::max(mx, host[4 * i + 1]);
+            const double a = host[4 * i], c = host[4 * i + 1];
+            mn = (a < mn || a != a) ? a : mn; mx = (c > mx || c != c) ? c : mx;      // a NaN extreme propagates, as numpy's does
             sum += host[4 * i + 2]; sq += host[4 * i + 3];
         }
         mean = sum / (double)count;
     }
     out4[0] = mn; out4[1] = mx; out4[2] = mean; out4[3] = sqrt(sq / (double)count);
+    return 0;
+}
+
+FDN_API int fdn_stats_slices_dev(fdn_handle h, const float* d_in, int nslices, size_t slice_elems, double centre, double* out)
+{
+    FDN_ENTER(h);
+    if (!d_in || !out) return fail("NULL pointer");
+    if (nslices <= 0 || !slice_elems) return fail("empty volume");
+    const int B = FDN_STATS_BLOCKS_PER_SLICE;
+    const int step = 4096;                         // slices per launch (the grid's y extent is limited to 65535)
+    if (ensure(h, h->partials, (size_t)std::min(nslices, step) * B * 4 * sizeof(double))) return -1;
+    std::vector<double> host((size_t)std::min(nslices, step) * B * 4);
+    for (int s0 = 0; s0 < nslices; s0 += step) {
+        const int n = std::min(step, nslices - s0);
+        launch_stats_slices(d_in + (size_t)s0 * slice_elems, n, slice_elems, centre, (double*)h->partials.p, h->stream);
+        FDN_HIP(hipGetLastError());
+        FDN_HIP(hipMemcpyAsync(host.data(), h->partials.p, (size_t)n * B * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        FDN_HIP(hipStreamSynchronize(h->stream));
+        for (int s = 0; s < n; s++) {
+            const double* p = host.data() + (size_t)s * B * 4;
+            double mn = p[0], mx = p[1], sum = 0, sq = 0;
+            for (int b = 0; b < B; b++) {
+                const double a = p[4 * b], c = p[4 * b + 1];
+                mn = (a < mn || a != a) ? a : mn; mx = (c > mx || c != c) ? c : mx;
+                sum += p[4 * b + 2]; sq += p[4 * b + 3];
+            }
+            double* o = out + (size_t)(s0 + s) * 4;
+            o[0] = mn; o[1] = mx; o[2] = sum; o[3] = sq;
+        }
+    }
+    return 0;
+}
+
+FDN_API int fdn_device_count(int* count_out)
+{
+    if (!count_out) return fail("count_out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count_out = n;
     return 0;
 }
 

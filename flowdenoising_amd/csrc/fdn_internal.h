@@ -83,6 +83,7 @@ struct Tuning {
     int fused_occ = 0;       // FDN_FUSED_OCC: pin the 3-iteration fused kernel's occupancy build (3, 4, 5)
     unsigned lds_pad = 0;    // FDN_LDS_PAD: extra dynamic LDS per workgroup (occupancy curves)
     int cus = 256;           // compute units of the handle's device
+    int shard_loopback = 0;  // fdn_filter_3d_sharded: the blocks a rank keeps also travel through the transport (send to self)
 };
 
 // Fused chain step (fdn_fused.hip): for every pair of the batch, the whole level-0 Farneback
@@ -117,6 +118,9 @@ void launch_permute(const float* in, float* out, int A, int B, int C, int64_t sa
 // sums[c] = numpy's float32 pairwise sum of in[8192 c .. 8192 c + 8191]
 void launch_np_chunk_sums(const float* in, size_t nchunks, float* sums, hipStream_t st);
 int launch_stats_partials(const float* in, size_t count, double centre, double* partials, int max_blocks, hipStream_t st);
+// per slice {min, max, sum, sum of squared deviations from centre}: FDN_STATS_BLOCKS_PER_SLICE partials of 4 doubles per slice
+constexpr int FDN_STATS_BLOCKS_PER_SLICE = 16;
+void launch_stats_slices(const float* in, int nslices, size_t slice_elems, double centre, double* partials, hipStream_t st);
 void launch_convert_f32(const void* in, int depth, float* out, size_t count, hipStream_t st);
 void launch_truncate_from_f32(const float* in, int depth, void* out, size_t count, hipStream_t st);
 int launch_sum_partials(const float* in, size_t count, double* partials, int max_blocks,

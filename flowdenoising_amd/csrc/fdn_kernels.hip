@@ -750,13 +750,15 @@ __global__ __launch_bounds__(256) void k_stats_partials(const float* __restrict_
     double mn = __builtin_inf(), mx = -__builtin_inf(), s = 0, q = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
         const double v = (double)in[i];
-        mn = v < mn ? v : mn; mx = v > mx ? v : mx;     // (a NaN voxel is skipped by both, as numpy's nanmin would; numpy's min propagates it)
+        // numpy's min / max propagate a NaN (seq:566's `np.max(filtered) < 256` is then False -> uint16; mrcfile's dmin /
+        // dmax are NaN): once an extreme is NaN every later comparison is false and it stays
+        mn = (v < mn || v != v) ? v : mn; mx = (v > mx || v != v) ? v : mx;
         s += v;
         q += (v - centre) * (v - centre);
     }
     for (int off = 32; off > 0; off >>= 1) {
         const double a = __shfl_down(mn, off, 64), b = __shfl_down(mx, off, 64);
-        mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+        mn = (a < mn || a != a) ? a : mn; mx = (b > mx || b != b) ? b : mx;
         s += __shfl_down(s, off, 64); q += __shfl_down(q, off, 64);
     }
     const int w = threadIdx.x >> 6;
@@ -764,11 +766,49 @@ __global__ __launch_bounds__(256) void k_stats_partials(const float* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < 4; k++) {
-            sh[0][0] = sh[k][0] < sh[0][0] ? sh[k][0] : sh[0][0]; sh[0][1] = sh[k][1] > sh[0][1] ? sh[k][1] : sh[0][1];
+            sh[0][0] = (sh[k][0] < sh[0][0] || sh[k][0] != sh[k][0]) ? sh[k][0] : sh[0][0];
+            sh[0][1] = (sh[k][1] > sh[0][1] || sh[k][1] != sh[k][1]) ? sh[k][1] : sh[0][1];
             sh[0][2] += sh[k][2]; sh[0][3] += sh[k][3];
         }
         for (int k = 0; k < 4; k++) partials[(size_t)blockIdx.x * 4 + k] = sh[0][k];
     }
+}
+
+// The same per SLICE, in a form that does not depend on how many slices the caller holds: slice s is reduced by
+// FDN_STATS_BLOCKS_PER_SLICE blocks of 256 threads striding over ITS elements only, partials[(s * B + b) * 4 ..]; the host
+// adds a slice's B partials in block order.  A Z-slab of a sharded volume therefore yields, slice for slice, the very
+// doubles the whole volume yields on one GPU -- the header statistics of a multi-GPU run are the single-GPU ones bit for bit.
+__global__ __launch_bounds__(256) void k_stats_slices(const float* __restrict__ in, size_t slice_elems, double centre, double* __restrict__ partials)
+{
+    __shared__ double sh[4][4];
+    const float* sl = in + (size_t)blockIdx.y * slice_elems;
+    double mn = __builtin_inf(), mx = -__builtin_inf(), s = 0, q = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < slice_elems; i += (size_t)gridDim.x * 256) {
+        const double v = (double)sl[i];
+        mn = (v < mn || v != v) ? v : mn; mx = (v > mx || v != v) ? v : mx;
+        s += v;
+        q += (v - centre) * (v - centre);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double a = __shfl_down(mn, off, 64), b = __shfl_down(mx, off, 64);
+        mn = (a < mn || a != a) ? a : mn; mx = (b > mx || b != b) ? b : mx;
+        s += __shfl_down(s, off, 64); q += __shfl_down(q, off, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[w][0] = mn; sh[w][1] = mx; sh[w][2] = s; sh[w][3] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) {
+            sh[0][0] = (sh[k][0] < sh[0][0] || sh[k][0] != sh[k][0]) ? sh[k][0] : sh[0][0];
+            sh[0][1] = (sh[k][1] > sh[0][1] || sh[k][1] != sh[k][1]) ? sh[k][1] : sh[0][1];
+            sh[0][2] += sh[k][2]; sh[0][3] += sh[k][3];
+        }
+        for (int k = 0; k < 4; k++) partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + k] = sh[0][k];
+    }
+}
+void launch_stats_slices(const float* in, int nslices, size_t slice_elems, double centre, double* partials, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_stats_slices, dim3(FDN_STATS_BLOCKS_PER_SLICE, (unsigned)nslices), dim3(256), 0, st, in, slice_elems, centre, partials);
 }
 int launch_stats_partials(const float* in, size_t count, double centre, double* partials, int max_blocks, hipStream_t st)
 {

@@ -236,7 +236,10 @@ def read_tiff(path, zrange=None, shape_only=False):
 class _TiffPages:
     """Page after page of an uncompressed multi-page TIFF: one strip and one IFD per page, little-endian; BigTIFF above 4 GiB."""
 
-    def __init__(self, f, shape, dtype, deflate=False):
+    def __init__(self, f, shape, dtype, deflate=False, first_page=0):
+        """first_page > 0 (uncompressed stacks only): this writer adds pages first_page ... of a file whose header and
+        earlier pages somebody else writes -- page positions of an uncompressed stack follow from the shape alone, so the
+        ranks of a multi-GPU run write their own Z-slabs into one file side by side."""
         self.deflate = bool(deflate)
         dtype = np.dtype(dtype)
         kind = dtype.kind
@@ -248,12 +251,29 @@ class _TiffPages:
         self.big = self.Z * (self.page_bytes + 512) + 1024 > (1 << 32) - (1 << 25)
         self.fmt_code = {"u": 1, "i": 2, "f": 3}[kind]
         self.desc = ('{"shape": [%d, %d, %d]}' % (self.Z, self.H, self.W)).encode() + b"\0"
-        if self.big:
-            f.write(b"II" + struct.pack("<HHHQ", 43, 8, 0, 16))
-        else:
-            f.write(b"II" + struct.pack("<HI", 42, 8))
-        self.pos = f.tell()
+        head = b"II" + (struct.pack("<HHHQ", 43, 8, 0, 16) if self.big else struct.pack("<HI", 42, 8))
+        self.pos = len(head)
         self.z = 0
+        if first_page == 0:
+            f.write(head)
+        else:
+            if self.deflate:
+                raise ValueError("pages of a compressed stack cannot be placed ahead of time")
+            for _ in range(first_page):          # where page `first_page` starts: the layout arithmetic of write_page
+                self.pos = self._layout(self.pos, self.z, self.page_bytes)[2]
+                self.z += 1
+
+    def _layout(self, pos, z, page_bytes):
+        """(IFD size with its out-of-line description, offset of the pixel data, offset of the next IFD) of page z at `pos`."""
+        big = self.big
+        n = 10 + (1 if z == 0 else 0)
+        ifd_size = (8 + n * 20 + 8) if big else (2 + n * 12 + 4)
+        extra = len(self.desc) if z == 0 and len(self.desc) > (8 if big else 4) else 0
+        data_off = pos + ifd_size + extra
+        data_off += (-data_off) % 16
+        next_ifd = data_off + page_bytes if z + 1 < self.Z else 0
+        next_ifd += (-next_ifd) % 2
+        return ifd_size, data_off, next_ifd
 
     def write_page(self, page):
         f, big, z, Z, H, W, desc, page_bytes = self.f, self.big, self.z, self.Z, self.H, self.W, self.desc, self.page_bytes
@@ -269,12 +289,9 @@ class _TiffPages:
         entries += [(273, 16 if big else 4, None), (277, 3, 1), (278, 4, H), (279, 16 if big else 4, page_bytes),
                     (339, 3, self.fmt_code)]
         n = len(entries)
-        ifd_size = (8 + n * 20 + 8) if big else (2 + n * 12 + 4)
+        ifd_size, data_off, next_ifd = self._layout(pos, z, page_bytes)
         extra = len(desc) if z == 0 and len(desc) > (8 if big else 4) else 0
-        data_off = pos + ifd_size + extra
-        data_off += (-data_off) % 16
-        next_ifd = data_off + page_bytes if z + 1 < Z else 0
-        next_ifd += (-next_ifd) % 2
+        assert n == 10 + (1 if z == 0 else 0)            # _layout counts the same entries
         buf = bytearray(struct.pack("<Q" if big else "<H", n))
         for tag, typ, val in entries:
             if tag == 273:
@@ -321,16 +338,22 @@ class VolumeWriter:
     GPU (seq:558-571's rules: MRC float32 with header statistics, else a TIFF stack of the array's dtype).
     `stats` (min / max / mean / std of the whole volume) is needed up front for an MRC header."""
 
-    def __init__(self, path, shape, dtype, stats=None):
+    def __init__(self, path, shape, dtype, stats=None, z0=0, create=True):
+        """z0 / create: a multi-GPU run writes ONE file from all its ranks -- rank 0 creates it (create=True, z0 = 0: the
+        header), the others open the existing file (create=False) and write the slices from their z0 on at the byte
+        offsets those slices have in the single-writer file (MRC: 1024 + z0 * Y * X * 4; TIFF: _TiffPages(first_page))."""
         self.mrc = is_mrc_output(path)
-        self.f = open(path, "wb")
+        self.f = open(path, "wb" if create else "r+b")
         self.shape = tuple(shape)
         if self.mrc:
-            if stats is None:
-                raise ValueError("an MRC header needs the volume's statistics")
-            self.f.write(_mrc_header(self.shape, stats))
+            if z0 == 0:
+                if stats is None:
+                    raise ValueError("an MRC header needs the volume's statistics")
+                self.f.write(_mrc_header(self.shape, stats))
+            else:
+                self.f.seek(1024 + z0 * self.shape[1] * self.shape[2] * 4)
         else:
-            self.pages = _TiffPages(self.f, self.shape, dtype)
+            self.pages = _TiffPages(self.f, self.shape, dtype, first_page=z0)
 
     def write_slab(self, slab):
         if self.mrc:

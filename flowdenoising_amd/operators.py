@@ -15,6 +15,8 @@ GPU; this module only marshals numpy arrays.  There is no CPU fallback.
     no_OF_filter(vol, kernel)                       seq:426-431
     FlowDenoising(P, vol, l, w, ...).filter(kernels)   par:297-304, 285-290
 """
+import threading
+
 import numpy as np
 
 from . import _lib
@@ -27,14 +29,17 @@ OF_POLY_SIGMA = 1.2    # seq:48
 SIGMA = 2.0            # seq:49
 
 _handles = {}
+_handles_lock = threading.Lock()
 
 
 def handle(device=0):
-    """Process-wide fdn handle for `device` (created on first use)."""
-    h = _handles.get(device)
-    if h is None:
-        h = _handles[device] = _lib.Handle(device)
-    return h
+    """Process-wide fdn handle for `device` (created on first use; the CLI's reservation thread and its main thread may
+    both be the first)."""
+    with _handles_lock:
+        h = _handles.get(device)
+        if h is None:
+            h = _handles[device] = _lib.Handle(device)
+        return h
 
 
 def _params(l, w, use_of=True, border_mode=_lib.BORDER_MEAN_PAD, chained=True):
@@ -187,20 +192,26 @@ def filter_3d_own_mean(vol, kernel, params, device=0, stats=None, float32_semant
             big = src.nbytes >= (8 << 20)
             # DMA at PCIe speed instead of staged copies.  A read-only memory map of the input file (the CLI's MRC path) is
             # page-locked where the runtime allows it: the upload then reads the page cache directly -- no host copy at all
-            pin_in = big and hu.host_register(src)
             try:
-                hu.h2d(d_out if raw_int else d_in, src)      # raw integers into the (larger) output buffer first
+                pin_in = big and hu.host_register(src)
+                try:
+                    hu.h2d(d_out if raw_int else d_in, src)      # raw integers into the (larger) output buffer first
+                finally:
+                    if pin_in:
+                        hu.host_unregister(src)
+                if hu is not h:
+                    hu.synchronize()
             finally:
-                if pin_in:
-                    hu.host_unregister(src)
+                if hu is not h:              # the upload's own handle goes away on error paths too; d_in / d_out outlive it
+                    hu.close()
             if wait_for is not None:
-                hu.synchronize()
-                hu.close()
                 wait_for()
             if raw_int:
                 h.convert_dev(d_out, src.dtype, d_in, src.size)      # float32 from there into d_in
             lap("h2d")
-            st_in = h.stats_dev(d_in, src.size) if (stats is not None or params.pad64 != params.pad64) else None
+            # (statistics from per-slice reductions added in slice order, fdn_stats_slices_dev: the form a multi-GPU run
+            # reproduces bit for bit from its slabs, so both write the same header)
+            st_in = h.stats_volume(d_in, src.shape) if (stats is not None or params.pad64 != params.pad64) else None
             if stats is not None:
                 stats["in"] = st_in
             if params.pad64 != params.pad64:      # an integer volume's float64 mean (seq:420), exact from the device copy
@@ -209,7 +220,7 @@ def filter_3d_own_mean(vol, kernel, params, device=0, stats=None, float32_semant
             mean = np.float32(params.pad64) if params.warp_mode == _lib.WARP_F64_PADDED else h.mean_dev(d_in, src.size)
             h.filter_3d_dev(d_in, d_out, src.shape, kernel, mean, params)
             if stats is not None or tiff_downcast:
-                st_out = h.stats_dev(d_out, src.size)
+                st_out = h.stats_volume(d_out, src.shape)
                 if stats is not None:
                     stats["out"] = st_out
             d_res = d_out

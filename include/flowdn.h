@@ -74,6 +74,9 @@ typedef struct fdn_sweep_params {
  * "OpenCV is loaded" state of the reference; gpu:92-103 (GPU_flower.__init__) is the
  * closest reference analogue. */
 int fdn_create(int device, fdn_handle* out);
+/* HIP devices visible to this process (0 when there is none or the runtime cannot start): what a rank of a multi-GPU run
+ * compares with the number of ranks to choose between one GPU each (RCCL) and sharing (include/flowdn_rccl.h). */
+int fdn_device_count(int* count_out);
 int fdn_destroy(fdn_handle h);
 const char* fdn_last_error(void);
 /* Enqueue on an external HIP stream instead (e.g. torch.cuda.current_stream().cuda_stream, so that
@@ -102,6 +105,9 @@ int fdn_mem_info(fdn_handle h, size_t* free_out, size_t* total_out);
  *   "fused_occ"    0 automatic, 3..5 one-band workgroups per CU of the 3-iteration fused kernel, 8 two bands per
  *                  8-wave workgroup (two workgroups per CU)
  *   "lds_pad"      bytes of extra dynamic LDS per workgroup of that kernel (occupancy curves)
+ *   "shard_loopback" 0/1  fdn_filter_3d_sharded: the blocks a rank keeps for itself travel through the transport too
+ *                  (a send to self inside the group; the mean through allgather_host even with one rank), so that
+ *                  ONE rank on one GPU issues the calls of an N > 1 run
  * No counterpart in the reference (cv2 has no such switches). */
 int fdn_set_option(fdn_handle h, const char* name, long value);
 
@@ -226,7 +232,13 @@ int fdn_sum_dev(fdn_handle h, const float* d_in, size_t count, double* sum_out);
  * mrcfile's set_data computes for the output file (seq:562-564: dmin, dmax, dmean, rms) and what seq:529-532 / 547-550
  * log about the input and output volumes -- taken where the volume already is instead of by numpy on the host
  * (six reductions over 2 GiB cost the reference's CLI about 2 s). */
-int fdn_stats_dev(fdn_handle h, const float* d_in, size_t count, double* out4);
+int fdn_stats_dev(fdn_handle h, const float* d_in, size_t count, double* out4);   /* a NaN voxel makes min and max NaN, as numpy's do */
+/* The same per slice, in a form that does not depend on how the volume is split into slabs: out[4 s ..] = {min, max, sum,
+ * sum of squared deviations from `centre`} of slice s (`slice_elems` floats each), every slice reduced in one fixed order.
+ * The caller adds the slices up in order (pass 1: centre = 0 -> the mean; pass 2: centre = mean -> the rms).  A rank of a
+ * multi-GPU run computes its slab's slices, the ranks all-gather them, and the header of the output file (seq:562-564)
+ * is the single-GPU one bit for bit. */
+int fdn_stats_slices_dev(fdn_handle h, const float* d_in, int nslices, size_t slice_elems, double centre, double* out);
 /* d_dst[i] = (float)d_src[i] for an 8- or 16-bit integer DEVICE array (depth: FDN_DEPTH_I16 / U16 / I8 / U8):
  * seq:517's `vol.astype(np.float32)` of a TIFF stack, and the device copy of an integer MRC, without a float32 copy
  * on the host (a 2048 x 2048 x 512 uint16 stack is 2 GiB on the wire instead of 8). */
@@ -248,12 +260,14 @@ int fdn_truncate_dev(fdn_handle h, const float* d_src, int depth, void* d_dst, s
  *   exchange        one batched group of point-to-point messages on DEVICE buffers, all of them at once: with RCCL
  *                   ncclGroupStart(); ncclSend / ncclRecv per message on `stream`; ncclGroupEnd();  with MPI
  *                   hipStreamSynchronize(stream), MPI_Isend / MPI_Irecv per message, MPI_Waitall.  Every rank calls it
- *                   the same number of times; a rank with nothing to move in a round passes n = 0.  No message to
- *                   oneself ever occurs.  Return 0 on success.
+ *                   the same number of times; a rank with nothing to move in a round passes n = 0.  A message to
+ *                   oneself occurs only under the "shard_loopback" test switch (fdn_set_option).  Return 0 on success.
  *   allgather_host  every rank contributes `bytes` from `send` (HOST memory); `recv` (HOST, world * bytes) receives all
  *                   contributions in rank order (ncclAllGather on a staging buffer, MPI_Allgather, ...).
- * The Python engine flowdenoising_amd/distributed.py (torch.distributed) implements the same schedule above the ABI;
- * the two give the same bits.  Integer-volume modes (fdn_sweep_params.warp_mode) are supported with pad64 given by the
+ * libflowdn_rccl.so (include/flowdn_rccl.h) implements both callbacks natively: RCCL over xGMI, a shared-memory
+ * rehearsal transport for ranks that share a GPU, and a null transport for per-rank overhead measurements.
+ * The Python engine flowdenoising_amd/distributed.py (torch.distributed; the gloo rehearsals of the CPU tests) implements
+ * the same schedule above the ABI; the two give the same bits.  Integer-volume modes (fdn_sweep_params.warp_mode) are supported with pad64 given by the
  * caller; otherwise the mean is computed here. */
 typedef struct fdn_msg {
     void* d_buf;        /* DEVICE memory of this rank */
@@ -294,8 +308,10 @@ int fdn_permute_dev(fdn_handle h, const float* d_in, float* d_out, int A, int B,
 #define FDN_TIMER_TRANSFER 5         /* H2D / D2H                                               */
 #define FDN_TIMER_FUSED 6            /* fused Farneback chain-step kernel (fast path)           */
 #define FDN_TIMER_ITER 7             /* one-iteration Farneback kernel (wide windows)            */
-#define FDN_TIMER_COLLECTIVE 8       /* multi-GPU exchanges; fed by the host layer (fdn_add_timer): the library is single-device */
-#define FDN_TIMER_COUNT 9
+#define FDN_TIMER_COLLECTIVE 8       /* multi-GPU exchanges: fdn_filter_3d_sharded times its fdn_comm.exchange calls on the stream
+                                        (time waiting for the slowest peer included); a host-level engine adds its own (fdn_add_timer) */
+#define FDN_TIMER_MEAN 9             /* fdn_filter_3d_sharded: the global mean (seq:420) from the ranks' chunk sums                     */
+#define FDN_TIMER_COUNT 10
 /* HIP-event timing of the phases above on the handle's stream.  Event pairs are recorded
  * asynchronously (no host sync inside the timed work) and resolved by fdn_get_timers, which
  * returns accumulated milliseconds and the number of timed launches per category. */

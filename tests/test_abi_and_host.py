@@ -257,3 +257,67 @@ def test_volume_writer_slab_by_slab_equals_whole_file_writers(tmp_path):
     assert np.array_equal(fio.read_mrc(str(tmp_path / "b.mrc"), mmap=True), v)
     with pytest.raises(ValueError, match="statistics"):
         fio.VolumeWriter(str(tmp_path / "c.mrc"), v.shape, np.float32)
+
+
+def test_several_writers_fill_one_file_like_a_single_writer(tmp_path):
+    """The ranks of `--gpus N` write their own Z-slabs into ONE output file (io.VolumeWriter(z0=..., create=False)): page /
+    slice positions follow from the shape alone, so writers that start at different slices, in any order, produce the
+    single writer's bytes (cli._run_sharded)."""
+    from flowdenoising_amd import io as fio
+    rng = np.random.default_rng(1)
+    for dt, shape in ((np.uint8, (9, 6, 10)), (np.uint16, (9, 7, 13)), (np.float32, (5, 8, 9))):
+        v = (rng.random(shape) * 200).astype(dt)
+        fio.write_tiff(str(tmp_path / "a.tif"), v)
+        parts = [(0, 2), (2, 6), (6, shape[0])] if shape[0] > 6 else [(0, 1), (1, 4), (4, shape[0])]
+        w0 = fio.VolumeWriter(str(tmp_path / "b.tif"), shape, dt, None, z0=0, create=True)       # rank 0 makes the file ...
+        for z0, z1 in reversed(parts[1:]):                                                       # ... the others fill theirs in first
+            w = fio.VolumeWriter(str(tmp_path / "b.tif"), shape, dt, None, z0=z0, create=False)
+            w.write_slab(v[z0:z1])
+            w.close()
+        w0.write_slab(v[parts[0][0]:parts[0][1]])
+        w0.close()
+        assert (tmp_path / "a.tif").read_bytes() == (tmp_path / "b.tif").read_bytes()
+        assert np.array_equal(fio.read_tiff(str(tmp_path / "b.tif")), v)
+    v = rng.random((7, 9, 11)).astype(np.float32)
+    st = fio.volume_stats(v)
+    fio.write_mrc(str(tmp_path / "a.mrc"), v, stats=st)
+    w0 = fio.VolumeWriter(str(tmp_path / "b.mrc"), v.shape, np.float32, st, z0=0, create=True)
+    w2 = fio.VolumeWriter(str(tmp_path / "b.mrc"), v.shape, np.float32, st, z0=5, create=False)
+    w1 = fio.VolumeWriter(str(tmp_path / "b.mrc"), v.shape, np.float32, st, z0=2, create=False)
+    w2.write_slab(v[5:]); w2.close()
+    w0.write_slab(v[:2]); w0.close()
+    w1.write_slab(v[2:5]); w1.close()
+    assert (tmp_path / "a.mrc").read_bytes() == (tmp_path / "b.mrc").read_bytes()
+
+
+def test_combine_slice_stats_matches_numpy_and_propagates_nan(fdn):
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal((6, 5, 7))
+    rows1 = np.array([[s.min(), s.max(), s.sum(), 0.0] for s in v])
+    mean = fdn._lib.combine_slice_stats(rows1, v.size)["mean"]
+    rows2 = np.array([[0, 0, 0, ((s - mean) ** 2).sum()] for s in v])
+    st = fdn._lib.combine_slice_stats(rows1, v.size, rows2)
+    assert st["min"] == v.min() and st["max"] == v.max()
+    assert abs(st["mean"] - v.mean()) < 1e-14 and abs(st["std"] - v.std()) < 1e-14
+    rows1[3, 0] = rows1[3, 1] = np.nan                 # a slice with a NaN voxel: numpy's min / max propagate it
+    st = fdn._lib.combine_slice_stats(rows1, v.size)
+    assert np.isnan(st["min"]) and np.isnan(st["max"])
+
+
+def test_product_does_not_import_torch():
+    """north_star: "PyTorch-ROCm is not needed here".  The drop-in (CLI single- and multi-GPU, operators, I/O, the launcher,
+    the ctypes layer, streaming) imports no torch at module level, and importing it all leaves torch out of sys.modules;
+    torch stays confined to distributed.py's gloo / RCCL rehearsal engine (imported lazily inside its classes) and bench.py."""
+    import subprocess
+    import sys
+    prog = ("import sys; sys.path.insert(0, %r)\n"
+            "import flowdenoising_amd, flowdenoising_amd.cli, flowdenoising_amd.launch, flowdenoising_amd.operators, flowdenoising_amd.io, "
+            "flowdenoising_amd.streaming, flowdenoising_amd.flower, flowdenoising_amd.distributed, flowdenoising_amd._lib\n"
+            "assert 'torch' not in sys.modules, 'torch imported'\nprint('ok')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-2000:]
+    bad = re.compile(r"^(import torch|from torch)", re.M)
+    for fn in ("cli.py", "launch.py", "operators.py", "io.py", "_lib.py", "streaming.py", "flower.py", "synth.py", "__init__.py"):
+        assert not bad.search(open(os.path.join(ROOT, "flowdenoising_amd", fn)).read()), fn
+    src = open(os.path.join(ROOT, "flowdenoising_amd", "cli.py")).read()
+    assert "torch.distributed" not in src.split('"""', 2)[2]        # (the module docstring may say what it no longer does)

@@ -603,3 +603,89 @@ def test_strict_order_mode_reproduces_opencvs_horizontal_running_sum(oracle, tmp
         outs[strict] = np.load(tmp_path / "o.npy")
     assert np.array_equal(outs["1"], want)
     assert not np.array_equal(outs["0"], want) and rel_err(outs["0"], want) < 1e-4
+
+
+# ---- the native transports (libflowdn_rccl.so): no torch in any of these processes ---------------------------------------
+def test_native_rccl_world_size_1_loopback(fdn, tmp_path):
+    """One real RCCL communicator made by libflowdn_rccl.so itself (ncclGetUniqueId / ncclCommInitRank, no torch in the
+    process): fdn_filter_3d_sharded in loopback mode sends the blocks a rank keeps to itself inside the group -- ncclSend /
+    ncclRecv under ncclGroupStart / End, the calls of an N > 1 run -- and takes the mean through ncclAllGather; the result
+    equals the single-GPU OF_filter bit for bit."""
+    vol = _vol((12, 70, 150), seed=35)
+    np.save(tmp_path / "v.npy", vol)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FDN_RANK", "FDN_WORLD", "FDN_RDV")}
+    env["FDN_SYSTEM_ROCM"] = "1"
+    sig = "1.0,0.5,1.0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_native_worker.py"), str(tmp_path / "v.npy"), str(tmp_path / "o"),
+                        sig, "0", "0", "5", "loopback"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    print(r.stdout.strip())
+    assert "transport: rccl" in r.stdout and "rank 0 of 1" in r.stdout
+    ks = [fdn.get_gaussian_kernel(float(s)) for s in sig.split(",")]
+    assert np.array_equal(np.load(f"{tmp_path}/o.0.npy"), fdn.OF_filter(vol, ks, 0, 5))
+
+
+@pytest.mark.parametrize("world,shape,sig,border,l", [(2, (12, 70, 150), "1.0,0.5,1.0", 0, 0), (3, (13, 64, 128), "1.0,-,0.5", 1, 1),
+                                                      (4, (10, 66, 140), "1.5,0.5,1.0", 0, 0)])
+def test_native_transport_multi_rank(fdn, tmp_path, world, shape, sig, border, l):
+    """N > 1 without torch: `world` rank processes started by flowdenoising_amd.launch.spawn run fdn_filter_3d_sharded on
+    the native transport and reproduce the single-GPU OF_filter bit for bit -- over RCCL where the node has a GPU per rank
+    (the driver's scaling box), through the shared-memory rehearsal transport where the ranks share GPU 0 (this box)."""
+    from flowdenoising_amd import launch
+    vol = _vol(shape, seed=33)
+    np.save(tmp_path / "v.npy", vol)
+    lines = []
+    env = dict(os.environ, FDN_SYSTEM_ROCM="1")
+    rc = launch.spawn([sys.executable, os.path.join(ROOT, "tests", "_native_worker.py"), str(tmp_path / "v.npy"), str(tmp_path / "o"),
+                       sig, str(border), str(l), "5"], world, env=env, relay=lines.append)
+    assert rc == 0, "".join(lines)
+    print("".join(lines).strip())
+    assert "transport:" in "".join(lines)
+    got = np.concatenate([np.load(f"{tmp_path}/o.{r}.npy") for r in range(world)])
+    ks = [None if s == "-" else fdn.get_gaussian_kernel(float(s)) for s in sig.split(",")]
+    assert np.array_equal(got, fdn.OF_filter(vol, ks, l, 5, border_mode=border))
+
+
+@pytest.mark.parametrize("suffix,dtype,compat", [("mrc", np.float32, "seq"), ("mrc", np.int16, "seq"), ("tif", np.uint16, "seq"), ("tif", np.float32, "par")])
+def test_cli_gpus_2_is_torch_free_and_writes_the_single_gpu_file(fdn, tmp_path, suffix, dtype, compat):
+    """`python flowdenoising.py --gpus 2`: two rank processes (subprocess.Popen, no torch.distributed.run), each reads its
+    own Z-slab, filters on the native transport and writes its slab into the output file at its byte offset; torch never
+    enters sys.modules (FDN_ASSERT_NO_TORCH) and the file equals the single-GPU run's byte for byte -- header statistics
+    and seq:566-571's uint8 / uint16 decision included."""
+    from flowdenoising_amd import io as fio
+    v = _vol((11, 40, 72), seed=12)
+    if np.issubdtype(dtype, np.integer):
+        v = np.round((v - v.min()) * (900.0 / (v.max() - v.min()))).astype(dtype)
+    src = str(tmp_path / f"in.{suffix}")
+    if suffix == "mrc":
+        _write_mrc_any(src, v)
+    else:
+        fio.write_tiff(src, v)
+    outs = []
+    for gpus in (1, 2):
+        dst = str(tmp_path / f"out{gpus}.{suffix}")
+        env = {k: val for k, val in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FDN_RANK", "FDN_WORLD", "FDN_RDV")}
+        env["FDN_ASSERT_NO_TORCH"] = "1"
+        cmd = [sys.executable, os.path.join(ROOT, "flowdenoising.py"), "-i", src, "-o", dst, "-s", "1.0", "0.5", "1.0", "--compat", compat, "-l", "0"]
+        if gpus > 1:
+            cmd += ["--gpus", str(gpus)]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(open(dst, "rb").read())
+    assert outs[0] == outs[1]
+
+
+def _write_mrc_any(path, vol):
+    """An MRC of the array's own mode (the product writer only writes mode 2)."""
+    import struct
+    mode = {np.dtype(np.int8): 0, np.dtype(np.int16): 1, np.dtype(np.float32): 2, np.dtype(np.uint16): 6}[vol.dtype]
+    nz, ny, nx = vol.shape
+    h = bytearray(1024)
+    struct.pack_into("<4i", h, 0, nx, ny, nz, mode)
+    struct.pack_into("<3i", h, 28, nx, ny, nz)
+    struct.pack_into("<3i", h, 64, 1, 2, 3)
+    h[208:212] = b"MAP "
+    h[212:216] = bytes([0x44, 0x44, 0, 0])
+    with open(path, "wb") as f:
+        f.write(h)
+        f.write(np.ascontiguousarray(vol).tobytes())
