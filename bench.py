@@ -334,7 +334,8 @@ def check_sharded(h, tr, dev, rank, world, shape, kernels, params, amplitude, sl
     full[parts[0][0]:parts[0][1]].copy_(slab_out)
     tr.exchange([(full[z0:z1].data_ptr(), (z1 - z0) * Y * X * 4, r, False) for r, (z0, z1) in enumerate(parts) if r != 0], 0)
     torch.cuda.synchronize()
-    vol = synth.make_volume(shape, seed=1234 + 3, amplitude=amplitude, xp=torch, device=dev)
+    # the volume the ranks filtered: the generator seeds a slab's noise by its first slice, so the whole is their concatenation
+    vol = torch.cat([synth.make_volume(shape, seed=1234 + 3, amplitude=amplitude, xp=torch, device=dev, z0=z0, zlen=z1 - z0) for z0, z1 in parts])
     single = torch.empty_like(vol)
     mean = h.mean_dev(vol.data_ptr(), vol.numel())
     h.filter_3d_dev(vol.data_ptr(), single.data_ptr(), shape, kernels, mean, params)

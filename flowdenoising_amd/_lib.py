@@ -164,7 +164,7 @@ class Transport:
 
     KINDS = {"rccl": TRANSPORT_RCCL, "shm": TRANSPORT_SHM, "null": TRANSPORT_NULL}
 
-    def __init__(self, kind, rank, world, device=0, rendezvous=None):
+    def __init__(self, kind, rank, world, device=-1, rendezvous=None):
         self._lib = load_rccl()
         self._t = ctypes.c_void_p()
         self.kind, self.rank, self.world, self.device = kind, int(rank), int(world), int(device)

@@ -416,7 +416,13 @@ FDN_API int fdn_transport_exchange(fdn_transport_t t, int n, const fdn_msg* msgs
     switch (t->kind) {
     case FDN_TRANSPORT_RCCL: return rccl_exchange(t, n, msgs, (hipStream_t)stream);
     case FDN_TRANSPORT_SHM: return shm_exchange(t, n, msgs, (hipStream_t)stream);
-    default: return 0;
+    default:
+        // NULL: nothing travels.  What would have been received is zero-filled on the stream, so that the passes of an
+        // overhead emulation run on finite numbers (uninitialised staging memory may hold NaNs) -- device >= 0 only
+        if (t->device >= 0)
+            for (int i = 0; i < n; i++)
+                if (!msgs[i].is_send && msgs[i].bytes) T_HIP(hipMemsetAsync(msgs[i].d_buf, 0, msgs[i].bytes, (hipStream_t)stream));
+        return 0;
     }
 }
 

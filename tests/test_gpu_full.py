@@ -194,7 +194,25 @@ def test_bench_gpus_2_from_a_bare_shell(fdn):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["backend"] in ("nccl", "gloo") and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["value"] > 0
+    assert d["backend"].split()[0] in ("rccl", "shm"), d["backend"]         # the native transport: no torch.distributed
+    assert len(d["phase_ms_per_step_per_rank"]["compute"]) == 2 and "exchange" in d["phase_ms_per_step_per_rank"]
+    # an N > 1 line carries its own correctness check: the gathered sharded output equals a single-GPU rerun bit for bit,
+    # and the oracle recomputed one target slice per pass
+    c = d["checked"]
+    assert c["ok"] and c["sharded_output_equals_single_gpu_rerun"] and c["bit_equal"] and len(c["slices"]) == 3
+
+
+def test_bench_gpus_2_python_engine(fdn):
+    """--engine python: the torch.distributed slab engine (gloo rehearsal on a one-GPU box, RCCL with two GPUs), started by
+    bench.py itself under torch.distributed.run."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--engine", "python", "--shape", "24,96,160", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["backend"] in ("nccl", "gloo") and d["value"] > 0
     assert len(d["phase_ms_per_step_per_rank"]["compute"]) == 2
 
 
