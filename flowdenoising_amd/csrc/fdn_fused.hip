@@ -48,6 +48,18 @@
 #include <utility>
 #include <vector>
 
+#ifdef FDN_CLOCK_STAMPS
+// Diagnostic build only (tools/build_variant.sh clock "-DFDN_CLOCK_STAMPS", tools/clock_stamps.py; never the product): every
+// workgroup's stage-A wave stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) around its row loop into a buffer
+// of their own that no kernel reads: the in-kernel clock is their ratio x 100 MHz (MI355X_MICROARCH.md, DVFS give-back 6).
+__device__ unsigned long long fdn_clock_stamp_buf[2 * 16384];
+extern "C" __attribute__((visibility("default"))) int fdn_debug_clock_stamps(unsigned long long* out, int n)
+{
+    if (n > 2 * 16384) n = 2 * 16384;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fdn_clock_stamp_buf), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? n : -1;
+}
+#endif
+
 namespace fdn {
 
 // Whole-wave lane shifts of an f64 on the VALU (DPP wave_shr:1 / wave_shl:1): lane i receives the
@@ -275,6 +287,9 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
         R0Px r0N;
         load_R(R0i, (unsigned)xc, r0N.r01, r0N.r23, r0N.r4);
         lds_barrier();
+#ifdef FDN_CLOCK_STAMPS
+        const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
         for (int t = 0; t < T; t++) {
             if (t < H) {
                 const float2 f = fN;
@@ -294,6 +309,13 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
             }
             lds_barrier();
         }
+#ifdef FDN_CLOCK_STAMPS
+        if (lane == 0 && half == 0) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            ::fdn_clock_stamp_buf[2 * (blockIdx.x & 16383)] = __builtin_amdgcn_s_memtime() - st_c0;
+            ::fdn_clock_stamp_buf[2 * (blockIdx.x & 16383) + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+        }
+#endif
         return;
     }
 
@@ -478,7 +500,9 @@ static void launch_variant(const float* Rstack, const float* stack, const float*
             (void)hipGetDevice(&dev);
             const std::pair<const void*, int> key((const void*)kern, dev);
             if (std::find(told.begin(), told.end(), key) == told.end()) {
-                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                // refused: nothing is launched and the runtime's last error stays set -- the caller's hipGetLastError()
+                // check after the launches of a chain step reports it (as fdn_iter.hip's launcher returns -1)
+                if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return;
                 told.push_back(key);
             }
         }

@@ -331,15 +331,19 @@ __global__ __launch_bounds__(256) void k_update_flow_scan_t(const float* __restr
 // this is the only difference: with it the GPU reproduces the OpenCV-order oracle bit for bit.
 // One workgroup per pair marches down the rows: all threads update the row's vertical running sums
 // in LDS, five threads (one per channel) walk the row serially, all threads solve.  Slow by design.
+// The row is walked in segments of S columns -- the chain's running value stays in its thread's register from one
+// segment to the next, the window sums of a segment are solved before the chain moves on -- so that the LDS holds the
+// row of vertical sums (40 B per column) plus ONE segment of window sums: rows up to about 3 800 columns fit
+// (configs[4]'s 2048-pixel rows in two segments; until round 4 the whole row's window sums were kept: W <= 2040).
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_update_flow_strict(const float* __restrict__ Rstack, const float* __restrict__ Min_base,
                                                             float* __restrict__ Mout_base, float* __restrict__ flow_base,
-                                                            PairBatch pb, int H, int W, int m, double scale)
+                                                            PairBatch pb, int H, int W, int m, double scale, int S)
 {
     extern __shared__ double sh[];
     const int P = W + 2 * (m + 1);               // a row of vsum with m+1 replicated entries either side
     double* vs = sh;                              // [5][P], entry x + m + 1 = column x
-    double* G = sh + 5 * (size_t)P;               // [5][W]
+    double* G = sh + 5 * (size_t)P;               // [5][S]: the window sums of the segment being solved
     const size_t HW = (size_t)H * W;
     const int b = blockIdx.x;
     const float* Mp = Min_base + (size_t)b * 5 * HW;
@@ -363,43 +367,52 @@ __global__ __launch_bounds__(256) void k_update_flow_strict(const float* __restr
             for (int c = 0; c < 5; c++) vs[c * P + x + m + 1] += (double)(p1[c * HW + x] - p0[c * HW + x]);
         }
         __syncthreads();
-        if (threadIdx.x < 5) {                    // the serial chain of one channel
+        double g = 0.;                            // the chain's running value (threads 0..4: one channel each), kept across segments
+        if (threadIdx.x < 5) {
             double* v = vs + threadIdx.x * P + m + 1;
             for (int k = 1; k <= m + 1; k++) { v[-k] = v[0]; v[W - 1 + k] = v[W - 1]; }
-            double g = v[0] * (double)(m + 2);
+            g = v[0] * (double)(m + 2);
             for (int x = 1; x < m; x++) g += v[x];
-            double* out = G + threadIdx.x * (size_t)W;
-            for (int x = 0; x < W; x++) {
-                g += v[x + m] - v[x - m - 1];
-                out[x] = g;
-            }
         }
-        __syncthreads();
-        for (int x = threadIdx.x; x < W; x += 256) {
-            double a[5];
-#pragma unroll
-            for (int c = 0; c < 5; c++) a[c] = G[c * (size_t)W + x];
-            const float2 f = solve_flow(a, scale);
-            const size_t o = (size_t)y * W + x;
-            flow[o] = f;
-            if (Mout) {
-                float mm[5];
-                compute_M(R0, R1, H, W, x, y, f.x, f.y, mm);
-#pragma unroll
-                for (int c = 0; c < 5; c++) Mout[c * HW + o] = mm[c];
+        for (int x0 = 0; x0 < W; x0 += S) {
+            const int x1 = x0 + S < W ? x0 + S : W;
+            if (threadIdx.x < 5) {                // the serial chain of one channel, columns [x0, x1)
+                const double* v = vs + threadIdx.x * P + m + 1;
+                double* out = G + threadIdx.x * (size_t)S - x0;
+                for (int x = x0; x < x1; x++) {
+                    g += v[x + m] - v[x - m - 1];
+                    out[x] = g;
+                }
             }
-        }
-        // the next row's vsum update is fenced from this row's chain by the barrier above; its chain from
-        // this row's solve by the barrier after that update
+            __syncthreads();
+            for (int x = x0 + threadIdx.x; x < x1; x += 256) {
+                double a[5];
+#pragma unroll
+                for (int c = 0; c < 5; c++) a[c] = G[c * (size_t)S + (x - x0)];
+                const float2 f = solve_flow(a, scale);
+                const size_t o = (size_t)y * W + x;
+                flow[o] = f;
+                if (Mout) {
+                    float mm[5];
+                    compute_M(R0, R1, H, W, x, y, f.x, f.y, mm);
+#pragma unroll
+                    for (int c = 0; c < 5; c++) Mout[c * HW + o] = mm[c];
+                }
+            }
+            __syncthreads();                      // the segment's window sums are consumed before the chain overwrites them;
+        }                                         // and the next row's vsum update comes after this row's last chain read
     }
 }
 
-static size_t strict_lds_bytes(int W, int winsize)
+// LDS: the row of vertical sums, and window sums for as long a segment as the rest of the 160 KB holds
+static int strict_segment(int W, int winsize)
 {
     const int m = winsize / 2;
-    return (5 * (size_t)(W + 2 * (m + 1)) + 5 * (size_t)W) * sizeof(double);
+    const long P = (long)W + 2 * (m + 1);
+    const long room = (160 * 1024) / (5 * (long)sizeof(double)) - P;      // doubles per channel left for a segment
+    return (int)(room < W ? room : W);
 }
-bool strict_order_supported(int W, int winsize) { return strict_lds_bytes(W, winsize) <= 160 * 1024; }
+bool strict_order_supported(int W, int winsize) { return strict_segment(W, winsize) >= 64; }
 
 // returns false when the row does not fit the LDS (the caller reports the error: strict mode never falls back silently)
 bool launch_update_flow_strict(const float* Rstack, const float* Min, float* Mout, float* flow, PairBatch pb,
@@ -407,12 +420,13 @@ bool launch_update_flow_strict(const float* Rstack, const float* Min, float* Mou
 {
     if (pb.npairs <= 0) return true;
     const int m = winsize / 2;
-    const size_t bytes = strict_lds_bytes(W, winsize);
-    if (bytes > 160 * 1024) return false;
+    const int S = strict_segment(W, winsize);
+    if (S < 64) return false;
+    const size_t bytes = (5 * (size_t)(W + 2 * (m + 1)) + 5 * (size_t)S) * sizeof(double);
     // per launch: the attribute belongs to the device's code object and handles may sit on different devices
     if (hipFuncSetAttribute((const void*)k_update_flow_strict, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
     const double scale = 1. / ((double)winsize * winsize);
-    hipLaunchKernelGGL(k_update_flow_strict, dim3(pb.npairs), dim3(256), bytes, st, Rstack, Min, Mout, flow, pb, H, W, m, scale);
+    hipLaunchKernelGGL(k_update_flow_strict, dim3(pb.npairs), dim3(256), bytes, st, Rstack, Min, Mout, flow, pb, H, W, m, scale, S);
     return true;
 }
 

@@ -44,6 +44,23 @@ def test_config0_full_size_mrc_cli(fdn, oracle, tmp_path):
 
 
 # ---- configs[2]: 1024 x 1024 x 512 float32, sigma = 2, Z then Y then X: every pass checked at full volume ------
+def test_config1_mean_padded_z_pass_spot_parity(fdn, oracle):
+    """BASELINE configs[1] as it is named: 512 x 512 x 256 float32, sigma = 2, OF along Z only, mean-padded ends (seq:88-89)
+    -- the whole Z pass on the GPU, then two target slices recomputed by the oracle from the 17 input slices that feed them:
+    one whose window reaches the mean padding, one interior.  Bit equality on 512 x 512 images (10 bands per pair)."""
+    from flowdenoising_amd.synth import make_volume
+    shape = (256, 512, 512)
+    vol = make_volume(shape, seed=1234 + 1, amplitude=100.0)
+    k = fdn.get_gaussian_kernel(2.0)
+    mean = vol.mean()
+    got = fdn.OF_filter(vol, [k, None, None], 0, 5)                   # seq:419-424 with the Z kernel only: its own mean
+    assert np.array_equal(got, fdn.OF_filter_along_Z(vol, k, 0, 5, mean))
+    for t in (2, 131, 255):
+        lo, hi = max(0, t - 8), min(shape[0], t + 9)
+        want = oracle.filter_axis_range(vol[lo:hi], 0, k, 0, 5, mean, t - lo, t - lo + 1, nthreads=8)
+        assert np.array_equal(got[t], want[t - lo]), t
+
+
 def test_config2_each_pass_of_the_full_volume(fdn, oracle):
     """The bench.py workload.  The three passes run on the whole 2 GiB volume in HBM (fdn_filter_axis_dev per
     pass, so that each intermediate is available); fdn_filter_3d_dev -- what bench.py times -- must give the

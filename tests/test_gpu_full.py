@@ -345,10 +345,11 @@ def test_paths_can_be_switched_on_a_live_handle(fdn, oracle):
 
 
 def test_strict_order_refuses_rows_it_cannot_hold(fdn):
-    """Strict mode never falls back silently: a row too wide for the LDS of its serial kernel is an error."""
+    """Strict mode never falls back silently: a row too wide for the LDS of its serial kernel (the row's vertical sums, 40 B
+    per column, must fit next to a segment of window sums: about 4 000 columns) is an error."""
     from flowdenoising_amd._lib import FlowdnError
     from flowdenoising_amd.operators import handle
-    vol = np.zeros((3, 4, 2300), np.float32)
+    vol = np.zeros((3, 4, 4200), np.float32)
     h = handle()
     h.set_option("strict_order", 1)
     try:
@@ -621,6 +622,26 @@ def test_strict_order_mode_reproduces_opencvs_horizontal_running_sum(oracle, tmp
         outs[strict] = np.load(tmp_path / "o.npy")
     assert np.array_equal(outs["1"], want)
     assert not np.array_equal(outs["0"], want) and rel_err(outs["0"], want) < 1e-4
+
+
+@pytest.mark.parametrize("shape,l,w", [((5, 24, 2048), 0, 5), ((4, 70, 2048), 3, 15), ((3, 20, 3000), 0, 7)])
+def test_strict_order_on_rows_of_2048_pixels_and_more(fdn, oracle, shape, l, w):
+    """configs[4]'s images have 2048-pixel rows: the strict mode's serial chain walks such a row in segments (its running
+    value stays in a register, one segment of window sums in LDS at a time), so OpenCV's own f64 order can be verified on
+    them too -- until round 4 the mode refused rows wider than about 2040.  Z pass, every slice compared with the
+    OpenCV-order oracle bit for bit."""
+    from flowdenoising_amd.operators import handle
+    from flowdenoising_amd.synth import make_volume
+    vol = make_volume(shape, seed=77, amplitude=100.0)
+    k = fdn.get_gaussian_kernel(0.5)
+    h = handle()
+    h.set_option("strict_order", 1)
+    try:
+        got = fdn.OF_filter_along_Z(vol, k, l, w, vol.mean())
+    finally:
+        h.set_option("strict_order", 0)
+    want = oracle.filter_along_axis(vol, 0, k, l, w, vol.mean(), nthreads=16)
+    assert np.array_equal(got, want)
 
 
 # ---- the native transports (libflowdn_rccl.so): no torch in any of these processes ---------------------------------------
