@@ -203,6 +203,32 @@ def test_bench_gpus_2_from_a_bare_shell(fdn):
     assert c["ok"] and c["sharded_output_equals_single_gpu_rerun"] and c["bit_equal"] and len(c["slices"]) == 3
 
 
+def test_bench_gpus_2_under_torch_distributed_run(fdn):
+    """The round driver's launch for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...`.  torch.distributed.run only starts the ranks: they find each other through
+    the rendezvous directory flowdenoising_amd.launch derives from their common parent and the port (no process group is
+    initialised), exchange through the native transport, and rank 0 prints the one line -- with its `checked` block."""
+    import json
+    import socket
+    pytest.importorskip("torch")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "FDN_RANK", "FDN_WORLD", "FDN_RDV")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shape", "24,96,160", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["backend"].split()[0] in ("rccl", "shm")
+    assert d["checked"]["ok"] and d["checked"]["sharded_output_equals_single_gpu_rerun"]
+    import glob
+    import tempfile
+    assert not glob.glob(os.path.join("/dev/shm", f"fdn_rdv_{os.getuid()}_{port}_*")) and not glob.glob(os.path.join(tempfile.gettempdir(), f"fdn_rdv_{os.getuid()}_{port}_*"))
+
+
 def test_bench_gpus_2_python_engine(fdn):
     """--engine python: the torch.distributed slab engine (gloo rehearsal on a one-GPU box, RCCL with two GPUs), started by
     bench.py itself under torch.distributed.run."""
@@ -645,7 +671,8 @@ def test_strict_order_on_rows_of_2048_pixels_and_more(fdn, oracle, shape, l, w):
 
 
 # ---- the native transports (libflowdn_rccl.so): no torch in any of these processes ---------------------------------------
-def test_native_rccl_world_size_1_loopback(fdn, tmp_path):
+@pytest.mark.parametrize("with_torch", [False, True])
+def test_native_rccl_world_size_1_loopback(fdn, tmp_path, with_torch):
     """One real RCCL communicator made by libflowdn_rccl.so itself (ncclGetUniqueId / ncclCommInitRank, no torch in the
     process): fdn_filter_3d_sharded in loopback mode sends the blocks a rank keeps to itself inside the group -- ncclSend /
     ncclRecv under ncclGroupStart / End, the calls of an N > 1 run -- and takes the mean through ncclAllGather; the result
@@ -653,7 +680,11 @@ def test_native_rccl_world_size_1_loopback(fdn, tmp_path):
     vol = _vol((12, 70, 150), seed=35)
     np.save(tmp_path / "v.npy", vol)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FDN_RANK", "FDN_WORLD", "FDN_RDV")}
-    env["FDN_SYSTEM_ROCM"] = "1"
+    if with_torch:       # bench.py's process: torch imported first, so libflowdn_rccl.so must sit on torch's bundled HIP runtime and RCCL
+        pytest.importorskip("torch")
+        env["FDN_TEST_IMPORT_TORCH"] = "1"
+    else:                # the CLI's rank processes: no torch, /opt/rocm's runtime
+        env["FDN_SYSTEM_ROCM"] = "1"
     sig = "1.0,0.5,1.0"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_native_worker.py"), str(tmp_path / "v.npy"), str(tmp_path / "o"),
                         sig, "0", "0", "5", "loopback"], env=env, capture_output=True, text=True, timeout=600)

@@ -46,14 +46,23 @@ res = {
                   "tools/ubench/fetch_calib.hip); WRITE_SIZE as is",
     "bytes_per_launch": nbytes, "pixels_per_launch": px, "bytes_per_pixel": nbytes / px,
 }
-if "SQ_INSTS_VALU" in mean and "GRBM_GUI_ACTIVE" in mean:
-    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; a wave64 VALU instruction holds its SIMD's issue for 4 cycles
+model_path = os.environ.get("FDN_VALU_MODEL", os.path.join(ROOT, "profiles", "r04_valu_model.json"))
+if "SQ_INSTS_VALU" in mean and "GRBM_GUI_ACTIVE" in mean and os.path.exists(model_path) and kern.startswith("k_farneback_fused"):
+    # Per-class issue model (tools/valu_model.py): the kernel's own instruction mix priced with the cycles each opcode was
+    # MEASURED to hold a SIMD at 4 waves per SIMD (tools/ubench/rates.hip, profiles/r04_valu_rates_256cus.txt) -- 3.03 cycles
+    # per VALU instruction on average for this kernel, not the flat 4 of rounds 1-3 (nor the guide's 2, which holds for
+    # v_add / v_mul / v_mov only).  GRBM_GUI_ACTIVE is summed over the 8 XCDs.
+    model = json.load(open(model_path))
+    per = model["per_band_row_step"]["issue_cycles"] / model["per_band_row_step"]["valu_instructions"]
     cycles = mean["GRBM_GUI_ACTIVE"] / 8
-    util = mean["SQ_INSTS_VALU"] * 4 / (1024 * cycles)
-    res["limiter"] = {"unit": "VALU issue", "utilisation": round(util, 3),
+    util = mean["SQ_INSTS_VALU"] * per / (1024 * cycles)
+    res["limiter"] = {"unit": "VALU issue (per-class model)", "utilisation": round(util, 3),
+                      "cycles_per_valu_instruction": round(per, 3),
                       "sq_insts_valu_per_launch": mean["SQ_INSTS_VALU"], "gpu_cycles_per_launch": cycles,
                       "lds_bank_conflict_share": round(mean.get("SQ_LDS_BANK_CONFLICT", 0) / max(mean.get("SQ_LDS_IDX_ACTIVE", 1), 1), 3),
-                      "source": "same --pmc passes (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))"}
+                      "source": "SQ_INSTS_VALU (executed, --pmc) x the kernel's mean issue cycles per instruction (profiles/r04_valu_model.json: "
+                                "static per-stage opcode counts x measured per-opcode cycles) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); "
+                                "in-kernel clock 2.05 GHz by s_memtime / s_memrealtime stamps (profiles/r04_clock_stamps.json)"}
 res["all_counters_mean_per_launch"] = mean
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("kernel", "bytes_per_pixel", "kernel_source_sha")}), res.get("limiter"))
