@@ -5,7 +5,7 @@ child process with FDN_CLI_TIMING set, and prints one JSON record: file read / H
 (from the CLI's own clock), the process's total wall time (interpreter start, imports and library load included) and
 the same volume's device-resident time for comparison.
 
-usage: cli_wall.py [config2|config4] [out.json]"""
+usage: cli_wall.py [config2|config4] [out.json] [gpus]      (gpus > 1: `--gpus N`; on a one-GPU box the ranks share it)"""
 import json
 import os
 import subprocess
@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "config2"
     out_json = sys.argv[2] if len(sys.argv) > 2 else None
+    gpus = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     import torch
     from flowdenoising_amd import io as fio, synth
     dev = torch.device("cuda", 0)
@@ -45,7 +46,10 @@ def main():
         nvox = int(np.prod(shape))
         del vol
         torch.cuda.empty_cache()
-        rec = {"workload": which, "shape": list(shape), "cli_args": args, "input_bytes": os.path.getsize(src), "file_dir": base}
+        if gpus > 1:
+            args = args + ["--gpus", str(gpus)]
+        rec = {"workload": which, "shape": list(shape), "cli_args": args, "input_bytes": os.path.getsize(src), "file_dir": base,
+               "gpus_visible": torch.cuda.device_count()}
         runs = []
         for it in range(2):           # the second run has the input in the page cache and the library's code object cached
             tj = os.path.join(td, "t.json")
@@ -66,7 +70,7 @@ def main():
         rec["runs"] = runs
         rec["output_bytes"] = os.path.getsize(dst)
         best = runs[-1]
-        pcie_plus_compute = best["h2d"] + best["compute"] + best["d2h"]
+        pcie_plus_compute = best["h2d"] + best["compute"] + best.get("d2h", best.get("d2h_write", 0.0))      # (--gpus N: rank 0's phases; h2d includes its slab read, d2h its file write)
         rec["pcie_plus_compute_s"] = round(pcie_plus_compute, 3)
         rec["wall_over_pcie_plus_compute"] = round(best["process_total"] / pcie_plus_compute, 2)
         rec["note"] = ("read / write: file <-> host array (page cache); h2d / compute / d2h: inside filter, synchronised between phases; "

@@ -3,7 +3,7 @@
 reads for roofline.traffic / roofline.limiter.  It is stamped with the hash of the kernel sources, the commit and
 the workload it was taken on; bench.py ignores it (traffic = null, loud warning) when any of them differs.
 
-usage: make_traffic_json.py <kernel substring> <out.json> <commit> [pmc glob] [levels winsize]"""
+usage: make_traffic_json.py <kernel substring> <out.json> <commit> [pmc glob] [levels winsize [Z,Y,X [sigma(s) [bench args]]]]"""
 import collections
 import csv
 import glob
@@ -26,7 +26,9 @@ mean = {k: sum(v) / len(v) for k, v in acc.items()}
 if "FETCH_SIZE" not in mean or "WRITE_SIZE" not in mean:
     sys.exit(f"no FETCH_SIZE/WRITE_SIZE rows for {kern} under {pat}")
 levels, winsize = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (0, 5)
-shape = [512, 1024, 1024]
+shape = [int(v) for v in sys.argv[7].split(",")] if len(sys.argv) > 7 else [512, 1024, 1024]
+sigma = (float(sys.argv[8]) if "," not in sys.argv[8] else sys.argv[8]) if len(sys.argv) > 8 else 2.0     # as bench.py's run_cfg has it
+bench_args = sys.argv[9] if len(sys.argv) > 9 else (f" --levels {levels} --winsize {winsize}" if (levels, winsize) != (0, 5) else "")
 # pixels of an AVERAGE launch, as bench.py prices it: with a pyramid a chain step is one launch (three for the one-iteration
 # kernel) per level and level k has 4^-k of the pixels; `kern` must then select the launches of every level
 px = shape[0] * shape[1] * shape[2] * sum(0.25 ** k for k in range(levels + 1)) / (levels + 1)
@@ -36,10 +38,10 @@ res = {
     "kernel": kern,
     "kernel_source_sha": bench.kernel_source_hash(),
     "commit": commit,
-    "command": "rocprofv3 --pmc <set> -- python bench.py" + (f" --levels {levels} --winsize {winsize}" if (levels, winsize) != (0, 5) else "")
+    "command": "rocprofv3 --pmc <set> -- python bench.py" + bench_args
                + " --steps 1 --warmup 0 --no-cpu-baseline --no-timers --no-check "
                "(separate passes per counter set, tools/profile_round.sh)",
-    "workload": {"shape": shape, "winsize": winsize, "levels": levels, "sigma": 2.0, "axes": "zyx"},
+    "workload": {"shape": shape, "winsize": winsize, "levels": levels, "sigma": sigma, "axes": "zyx"},
     "launches_averaged": len(acc["FETCH_SIZE"]),
     "fetch_size_kib_per_launch": mean["FETCH_SIZE"], "write_size_kib_per_launch": mean["WRITE_SIZE"],
     "correction": "FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM section; re-checked on known byte counts by "
