@@ -37,9 +37,10 @@
 //   matrix rows over from the hand-over slot of the lane that owns the border column, so the ordinary
 //   lane shifts deliver the border column's running sums to the windows that reach outside.  After the
 //   lane shifts only the lanes whose result is used stay active (EXEC mask).
-//   Measured (MI355X, 512 targets of 1024 x 1024): 14.4 ms per launch, VALU issue 96 % busy at the
-//   2.05 GHz the socket's 1400 W power cap leaves it (DESIGN.md 3.2 has the history and the variants
-//   that lost).
+//   Measured (MI355X, 512 targets of 1024 x 1024): 14.4 ms per launch; the VALU stream fills 0.7-0.8 of the SIMDs'
+//   issue cycles (per-opcode costs measured by tools/ubench/rates.hip: 3.03 cycles per instruction for this mix) at the
+//   2.05 GHz the socket's 1400 W power cap leaves it (in-kernel s_memtime stamps; DESIGN.md 3.2 has the history and the
+//   variants that lost).
 #include "fdn_internal.h"
 #include "fdn_device.h"
 #include <stdlib.h>
@@ -64,8 +65,8 @@ namespace fdn {
 
 // Whole-wave lane shifts of an f64 on the VALU (DPP wave_shr:1 / wave_shl:1): lane i receives the
 // value of lane i-1 (i+1); the lane shifted in from outside the wave reads 0 (bound_ctrl), which only
-// reaches halo lanes whose results are never used.  Measured on MI355X (tools/ubench/rates.hip): ~5 cycles per v_mov_dpp per
-// SIMD against 24 cycles per ds_bpermute_b32 on the one LDS pipe the four SIMDs share.  (Also measured: the window
+// reaches halo lanes whose results are never used.  Measured on MI355X (tools/ubench/rates.hip): 3.2 cycles per v_mov_dpp per
+// SIMD at four waves per SIMD against 19-24 cycles per ds_bpermute_b32 on the one LDS pipe the four SIMDs share.  (Also measured: the window
 // through an LDS row per stage -- 5 ds_write_b64 + 10 ds_read2_b64 in place of 40 v_mov_dpp per row step, the R1
 // window cut to D = 4 to make room: 18.9 ms per launch against 17.8 with D = 4 alone and 16.9 as built.)
 static __device__ __forceinline__ double wave_shr1(double v)

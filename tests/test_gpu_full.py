@@ -670,6 +670,35 @@ def test_strict_order_on_rows_of_2048_pixels_and_more(fdn, oracle, shape, l, w):
     assert np.array_equal(got, want)
 
 
+def test_volume_statistics_slice_form_and_nan(fdn):
+    """fdn_stats_slices_dev / Handle.stats_volume (the header statistics of the output file, seq:562-564, taken slice by slice so
+    that a multi-GPU run reproduces them bit for bit): numpy's min / max exactly, mean and rms to float64 round-off, the same four
+    numbers whether the slices are reduced in one call or slab by slab; a NaN voxel makes min and max NaN as numpy's do (seq:566's
+    `np.max(filtered) < 256` then picks uint16), in fdn_stats_dev as well."""
+    from flowdenoising_amd import _lib
+    from flowdenoising_amd.operators import handle
+    rng = np.random.default_rng(5)
+    v = (rng.standard_normal((9, 37, 53)) * 40 + 7).astype(np.float32)
+    h = handle()
+    d = h.malloc(v.nbytes)
+    try:
+        h.h2d(d, v)
+        st = h.stats_volume(d, v.shape)
+        v64 = v.astype(np.float64)
+        assert st["min"] == v.min() and st["max"] == v.max()
+        assert abs(st["mean"] - v64.mean()) < 1e-12 and abs(st["std"] - v64.std()) < 1e-11
+        per = v[0].size
+        rows = np.concatenate([h.stats_slices_dev(d, 4, per, 0.0), h.stats_slices_dev(d + 4 * per * 4, 5, per, 0.0)])      # two "slabs"
+        assert np.array_equal(rows, h.stats_slices_dev(d, 9, per, 0.0))
+        assert _lib.combine_slice_stats(rows, v.size)["mean"] == st["mean"]
+        v[4, 5, 6] = np.nan
+        h.h2d(d, v)
+        for st in (h.stats_volume(d, v.shape), h.stats_dev(d, v.size)):
+            assert np.isnan(st["min"]) and np.isnan(st["max"]) and np.isnan(st["mean"])
+    finally:
+        h.free(d)
+
+
 # ---- the native transports (libflowdn_rccl.so): no torch in any of these processes ---------------------------------------
 @pytest.mark.parametrize("with_torch", [False, True])
 def test_native_rccl_world_size_1_loopback(fdn, tmp_path, with_torch):
