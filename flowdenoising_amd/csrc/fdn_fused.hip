@@ -38,7 +38,7 @@
 //   lane shifts deliver the border column's running sums to the windows that reach outside.  After the
 //   lane shifts only the lanes whose result is used stay active (EXEC mask).
 //   Measured (MI355X, 512 targets of 1024 x 1024): 14.4 ms per launch; the VALU stream fills 0.7-0.8 of the SIMDs'
-//   issue cycles (per-opcode costs measured by tools/ubench/rates.hip: 3.03 cycles per instruction for this mix) at the
+//   issue cycles (per-opcode costs measured by tools/ubench/rates.hip: 2.89 cycles per instruction for this mix) at the
 //   2.05 GHz the socket's 1400 W power cap leaves it (in-kernel s_memtime stamps; DESIGN.md 3.2 has the history and the
 //   variants that lost).
 #include "fdn_internal.h"

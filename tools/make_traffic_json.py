@@ -51,7 +51,7 @@ res = {
 model_path = os.environ.get("FDN_VALU_MODEL", os.path.join(ROOT, "profiles", "r04_valu_model.json"))
 if "SQ_INSTS_VALU" in mean and "GRBM_GUI_ACTIVE" in mean and os.path.exists(model_path) and kern.startswith("k_farneback_fused"):
     # Per-class issue model (tools/valu_model.py): the kernel's own instruction mix priced with the cycles each opcode was
-    # MEASURED to hold a SIMD at 4 waves per SIMD (tools/ubench/rates.hip, profiles/r04_valu_rates_256cus.txt) -- 3.03 cycles
+    # MEASURED to hold a SIMD at 4 waves per SIMD (tools/ubench/rates.hip, profiles/r04_valu_rates_256cus.txt) -- 2.89 cycles
     # per VALU instruction on average for this kernel, not the flat 4 of rounds 1-3 (nor the guide's 2, which holds for
     # v_add / v_mul / v_mov only).  GRBM_GUI_ACTIVE is summed over the 8 XCDs.
     model = json.load(open(model_path))

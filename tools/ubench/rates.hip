@@ -19,7 +19,7 @@ enum Op { ADD_F32, FMA_F32, MUL_F32, PK_ADD_F32, PK_MUL_F32, PK_FMA_F32, ADD_F64
           MOV_B32, MOV_DPP_WAVE_SHR, MOV_DPP_ROW_SHR, CNDMASK, MED3_I32, ADD_U32, MUL_U24, MAD_U24, RNDNE_F32, LDS_READ_B128, LDS_READ_B64,
           LDS_READ2_B32, LDS_WRITE_B64, BPERMUTE, NOPS,
           CNDMASK_SGPR, CMP_CNDMASK, CMP_F32, CMP_E64, LSHL, AND_B32, SUB_F32, FLOOR_F32, CVT_I32_F32, CVT_F32_UBYTE0, MOV_B64, FMAC_F64, ADD_LSHL, ASHR,
-          FMAC_F32, MAX_F32, MED3_F32, CVT_F64_U32, LDS_WRITE2ST64_B32, READFIRSTLANE };
+          FMAC_F32, MAX_F32, MED3_F32, CVT_F64_U32, LDS_WRITE2ST64_B32, READFIRSTLANE, CMP_CNDMASK_SGPR };
 
 template <int OP> __global__ void __launch_bounds__(1024) k(unsigned long long* stamps, float seed)
 {
@@ -93,6 +93,7 @@ template <int OP> __global__ void __launch_bounds__(1024) k(unsigned long long* 
 #define A_MED3_F32(i) asm volatile("v_med3_f32 %0, %0, %1, %1" : "+v"(f[i]) : "v"(c));
 #define A_CVT_D_U(i) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(d[i]) : "v"(iv[i]));
 #define A_LDSW2ST(i) asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" :: "v"(a32), "v"(f[i]), "v"(f[(i + 1) & 15]), "n"(i & 7), "n"((i & 7) + 8) : "memory");
+#define A_CMP_CND_S(i) asm volatile("v_cmp_lt_f32_e64 %1, %2, %0\n\tv_cndmask_b32_e64 %0, %0, %2, %1" : "+v"(f[i]), "=&s"(sm[i & 3]) : "v"(c));
 #define A_RFL(i) asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(si[i & 3]) : "v"(iv[i]));
         if (OP == ADD_F32) { REP16(A_ADD_F32) }
         if (OP == FMA_F32) { REP16(A_FMA_F32) }
@@ -141,6 +142,7 @@ template <int OP> __global__ void __launch_bounds__(1024) k(unsigned long long* 
         if (OP == CVT_F64_U32) { REP16(A_CVT_D_U) }
         if (OP == LDS_WRITE2ST64_B32) { REP16(A_LDSW2ST) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
         if (OP == READFIRSTLANE) { REP16(A_RFL) }
+        if (OP == CMP_CNDMASK_SGPR) { REP16(A_CMP_CND_S) }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -204,14 +206,15 @@ int main(int argc, char** argv)
     ROW(MOV_B32, "v_mov_b32")
     ROW(MOV_DPP_WAVE_SHR, "v_mov_b32_dpp wave_shr:1")
     ROW(MOV_DPP_ROW_SHR, "v_mov_b32_dpp row_shr:1")
-    ROW(CNDMASK, "v_cndmask_b32")
+    ROW(CNDMASK, "v_cndmask_b32 (VCC never written)")
     ROW(MED3_I32, "v_med3_i32")
     ROW(ADD_U32, "v_add_u32")
     ROW(MUL_U24, "v_mul_u32_u24")
     ROW(MAD_U24, "v_mad_u32_u24")
     ROW(RNDNE_F32, "v_rndne_f32")
     ROW(CNDMASK_SGPR, "v_cndmask_b32_e64 (sgpr)")
-    ROW(CMP_CNDMASK, "v_cmp_lt_f32+v_cndmask /2")
+    ROW(CMP_CNDMASK, "v_cmp_lt_f32 + v_cndmask (pair)")
+    ROW(CMP_CNDMASK_SGPR, "v_cmp_e64 + v_cndmask_e64 (pair)")
     ROW(CMP_F32, "v_cmp_lt_f32 vcc")
     ROW(CMP_E64, "v_cmp_lt_f32_e64 sgpr")
     ROW(LSHL, "v_lshlrev_b32")

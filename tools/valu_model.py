@@ -63,8 +63,9 @@ def cost_of(op, rates, unknown):
     if base.startswith("v_cndmask_b32"):
         if op.endswith("_e64"):
             return rates["v_cndmask_b32_e64 (sgpr)"], "select (SGPR-pair mask)"
-        # a VCC select behind the compare that made its mask: the measured pair minus the compare
-        return 2 * rates["v_cmp_lt_f32+v_cndmask /2"] - rates["v_cmp_lt_f32 vcc"], "select (VCC mask)"
+        # a VCC select behind the compare that made its mask: the measured (compare, select) pair minus the compare.  (Sixteen
+        # selects in a row on a VCC nobody has written cost 12.7 cycles each in the same table: not a pattern compiled code has.)
+        return rates["v_cmp_lt_f32 + v_cndmask (pair)"] - rates["v_cmp_lt_f32 vcc"], "select (VCC mask)"
     if base.startswith("v_cmp"):
         return (rates["v_cmp_lt_f32_e64 sgpr"] if op.endswith("_e64") else rates["v_cmp_lt_f32 vcc"]), "compare"
     row = ROW.get(base)
