@@ -366,9 +366,17 @@ def main():
     ngpu = torch.cuda.device_count()
     rehearsal = world > 1 and ngpu < world    # fewer GPUs than ranks (a one-GPU box): the ranks share GPUs and exchange through
     tr = dist = None                          # host memory -- exercises every line of the N > 1 path, its numbers mean nothing
+    fallback = None
     if world > 1 and a.engine == "native":
-        tr, device = launch.make_transport(rank, world, local_rank, rdv)      # RCCL, or shared memory when ranks share a GPU
-    else:
+        try:
+            tr, device = launch.make_transport(rank, world, local_rank, rdv)      # RCCL, or shared memory when ranks share a GPU
+        except Exception as e:      # e.g. the native library cannot be loaded on this node: under torch.distributed.run the
+            if "MASTER_PORT" not in os.environ:      # torch.distributed engine can still carry the run (said so in the line)
+                raise
+            fallback = f"native transport unavailable ({type(e).__name__}: {e}); torch.distributed slab engine used instead"
+            print("bench.py: WARNING: " + fallback, file=sys.stderr)
+            a.engine = "python"
+    if tr is None:
         device = local_rank % max(ngpu, 1)
     torch.cuda.set_device(device)
     dev = torch.device("cuda", device)
@@ -511,6 +519,8 @@ def main():
         }
         if tr is not None:
             res["transport"] = tr.describe()
+        if fallback:
+            res["transport_fallback"] = fallback
         # whole path against the SURVEY 8(d) stage list (4832 B/voxel/axis at sigma=2): what an UNFUSED implementation
         # would have to move; above the HBM peak it measures traffic removed by fusion, not bandwidth
         path_bytes = sum(24 + (k.size - 1) * 300 + 8 for k in kernels if k is not None)
