@@ -1,5 +1,6 @@
 """One-off randomised parity campaign: many more random sweep configurations than the test suite holds.
-usage: random_campaign.py [n] [seed] [wide]   -- `wide`: windows 10 .. 31 (the one-iteration kernel) instead of 3 .. 15"""
+usage: random_campaign.py [n] [seed] [wide|strict]   -- `wide`: windows 10 .. 31 (the one-iteration kernel) instead of 3 .. 15;
+`strict`: strict_order on (OpenCV's own f64 summation order, segment-walked rows): every case must then be bit-identical"""
 import sys, importlib.util, numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 spec = importlib.util.spec_from_file_location("tp", "tests/test_gpu_parity.py"); tp = importlib.util.module_from_spec(spec); spec.loader.exec_module(tp)
@@ -13,6 +14,9 @@ if len(sys.argv) > 3 and sys.argv[3] == "wide":
     rng = np.random.default_rng(99)
     cases = [(shape, axis, l, int(rng.choice([10, 11, 13, 15, 15, 17, 21, 31])), sigma, border, chained, seed)
              for (shape, axis, l, w, sigma, border, chained, seed) in cases]
+if len(sys.argv) > 3 and sys.argv[3] == "strict":
+    from flowdenoising_amd.operators import handle
+    handle().set_option("strict_order", 1)
 for i, (shape, axis, l, w, sigma, border, chained, seed) in enumerate(cases):
     vol = tp._vol(shape, seed=seed)
     k = fdn.get_gaussian_kernel(sigma)
