@@ -412,7 +412,8 @@ static int strict_segment(int W, int winsize)
     const long room = (160 * 1024) / (5 * (long)sizeof(double)) - P;      // doubles per channel left for a segment
     return (int)(room < W ? room : W);
 }
-bool strict_order_supported(int W, int winsize) { return strict_segment(W, winsize) >= 64; }
+// (a segment shorter than the row is worth its two barriers only from 64 columns up; a narrow row is one segment)
+bool strict_order_supported(int W, int winsize) { const int S = strict_segment(W, winsize); return S >= (W < 64 ? W : 64) && S >= 1; }
 
 // returns false when the row does not fit the LDS (the caller reports the error: strict mode never falls back silently)
 bool launch_update_flow_strict(const float* Rstack, const float* Min, float* Mout, float* flow, PairBatch pb,
@@ -421,7 +422,7 @@ bool launch_update_flow_strict(const float* Rstack, const float* Min, float* Mou
     if (pb.npairs <= 0) return true;
     const int m = winsize / 2;
     const int S = strict_segment(W, winsize);
-    if (S < 64) return false;
+    if (!strict_order_supported(W, winsize)) return false;
     const size_t bytes = (5 * (size_t)(W + 2 * (m + 1)) + 5 * (size_t)S) * sizeof(double);
     // per launch: the attribute belongs to the device's code object and handles may sit on different devices
     if (hipFuncSetAttribute((const void*)k_update_flow_strict, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;

@@ -650,9 +650,10 @@ def test_strict_order_mode_reproduces_opencvs_horizontal_running_sum(oracle, tmp
     assert not np.array_equal(outs["0"], want) and rel_err(outs["0"], want) < 1e-4
 
 
-@pytest.mark.parametrize("shape,l,w", [((5, 24, 2048), 0, 5), ((4, 70, 2048), 3, 15), ((3, 20, 3000), 0, 7)])
+@pytest.mark.parametrize("shape,l,w", [((5, 24, 2048), 0, 5), ((4, 70, 2048), 3, 15), ((3, 20, 3000), 0, 7), ((4, 9, 63), 0, 15), ((3, 5, 3), 0, 5)])
 def test_strict_order_on_rows_of_2048_pixels_and_more(fdn, oracle, shape, l, w):
-    """configs[4]'s images have 2048-pixel rows: the strict mode's serial chain walks such a row in segments (its running
+    """(The last two shapes: rows narrower than a segment's minimum are one segment.)
+    configs[4]'s images have 2048-pixel rows: the strict mode's serial chain walks such a row in segments (its running
     value stays in a register, one segment of window sums in LDS at a time), so OpenCV's own f64 order can be verified on
     them too -- until round 4 the mode refused rows wider than about 2040.  Z pass, every slice compared with the
     OpenCV-order oracle bit for bit."""
