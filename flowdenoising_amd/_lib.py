@@ -35,7 +35,7 @@ class SweepParams(ctypes.Structure):
         return c
 
 
-WARP_F32, WARP_F64_PADDED, WARP_ROUND_INT = 0, 1, 2
+WARP_F32, WARP_F64_PADDED, WARP_ROUND_INT, WARP_FIXED_U8 = 0, 1, 2, 3
 DEPTH_F32, DEPTH_F64, DEPTH_I16, DEPTH_U16, DEPTH_I8, DEPTH_U8 = range(6)
 DEPTHS = {np.dtype(np.float32): DEPTH_F32, np.dtype(np.float64): DEPTH_F64, np.dtype(np.int16): DEPTH_I16,
           np.dtype(np.uint16): DEPTH_U16, np.dtype(np.int8): DEPTH_I8, np.dtype(np.uint8): DEPTH_U8}

@@ -308,7 +308,7 @@ static int check_params(const fdn_sweep_params* p, int K)
         if (p->iters < 0) return fail("iters must be >= 0");
         if (p->levels < 0) return fail("levels must be >= 0");
     }
-    if (p->warp_mode < 0 || p->warp_mode > 2) return fail("warp_mode must be FDN_WARP_F32, _F64_PADDED or _ROUND_INT, got %d", p->warp_mode);
+    if (p->warp_mode < 0 || p->warp_mode > 3) return fail("warp_mode must be FDN_WARP_F32, _F64_PADDED, _ROUND_INT or _FIXED_U8, got %d", p->warp_mode);
     if (p->warp_mode == FDN_WARP_F64_PADDED && p->border_mode != FDN_BORDER_MEAN_PAD)
         return fail("FDN_WARP_F64_PADDED belongs to the mean-padded volume of seq:88-89 (border_mode FDN_BORDER_MEAN_PAD)");
     if (p->warp_mode == FDN_WARP_F64_PADDED && (p->pad_lo < 0 || p->pad_hi < 0)) return fail("pad_lo / pad_hi must be >= 0");
@@ -321,6 +321,7 @@ static WarpMode warp_mode_of(const fdn_sweep_params* p, int S, int r)
 {
     WarpMode wm;
     wm.kind = p->warp_mode;
+    if (wm.kind == FDN_WARP_FIXED_U8) { wm.kind = FDN_WARP_ROUND_INT; wm.fixed8 = 1; wm.lo = 0.f; wm.hi = 255.f; return wm; }   // the ROUND_INT kernels, their remap in 8-bit fixed point
     if (wm.kind == FDN_WARP_F64_PADDED) { wm.pad_lo = p->pad_lo; wm.pad_hi = S + 2 * r - p->pad_hi; wm.pad64 = p->pad64; }
     if (wm.kind == FDN_WARP_ROUND_INT) { wm.lo = (float)p->round_lo; wm.hi = (float)p->round_hi; }
     return wm;
@@ -1577,8 +1578,7 @@ FDN_API int fdn_warp_typed(fdn_handle h, const void* reference, int depth, ptrdi
     FDN_ENTER(h);
     if (check_warp_args(reference, flow, dst, H, W)) return -1;
     if (depth == FDN_DEPTH_I8) return fail("cv2.remap does not support 8-bit signed images (the reference raises there)");
-    if (depth == FDN_DEPTH_U8) return fail("cv2.remap interpolates 8-bit unsigned images in fixed point; that path is not restated");
-    if (depth != FDN_DEPTH_F64 && depth != FDN_DEPTH_I16 && depth != FDN_DEPTH_U16) return fail("unknown image depth %d (FDN_DEPTH_*)", depth);
+    if (depth != FDN_DEPTH_F64 && depth != FDN_DEPTH_I16 && depth != FDN_DEPTH_U16 && depth != FDN_DEPTH_U8) return fail("unknown image depth %d (FDN_DEPTH_*)", depth);
     const size_t HW = (size_t)H * W;
     hipStream_t st = h->stream;
     if (depth == FDN_DEPTH_F64) {      // remapBilinear<Cast<double, double>, ., float>: doubles in, doubles out
@@ -1604,7 +1604,7 @@ FDN_API int fdn_warp_typed(fdn_handle h, const void* reference, int depth, ptrdi
         return 0;
     }
     // 16-bit integers: remapBilinear<Cast<float, T>>: float arithmetic on the (exactly converted) values, then
-    // saturate_cast<T>(float) = cvRound (half to even), clamped to the type's range
+    // saturate_cast<T>(float) = cvRound (half to even), clamped to the type's range; uint8: fixed point (remap_finish_u8)
     if (ensure(h, h->pair, HW * 4 * 4)) return -1;
     if (ensure_pinned(h, HW * 4 * 4)) return -1;
     float* d_src = (float*)h->pair.p;
@@ -1617,13 +1617,17 @@ FDN_API int fdn_warp_typed(fdn_handle h, const void* reference, int depth, ptrdi
         memcpy(stage + HW, flow, HW * 8);
         FDN_HIP(hipMemcpyAsync(d_src, stage, HW * 12, hipMemcpyHostToDevice, st));
     }
-    launch_warp(d_src, d_flow, d_dst, H, W, st);
+    if (depth == FDN_DEPTH_U8) launch_warp_u8(d_src, d_flow, d_dst, H, W, st);     // 8-bit fixed-point interpolation: integers already
+    else launch_warp(d_src, d_flow, d_dst, H, W, st);
     FDN_HIP(hipGetLastError());
     ScopedTimer t(h, FDN_TIMER_TRANSFER);
     FDN_HIP(hipMemcpyAsync(stage + 3 * HW, d_dst, HW * 4, hipMemcpyDeviceToHost, st));
     FDN_HIP(hipStreamSynchronize(st));
     const float* res = stage + 3 * HW;
-    if (depth == FDN_DEPTH_I16) {
+    if (depth == FDN_DEPTH_U8) {
+        uint8_t* o = (uint8_t*)dst;
+        for (size_t i = 0; i < HW; i++) o[i] = (uint8_t)res[i];
+    } else if (depth == FDN_DEPTH_I16) {
         int16_t* o = (int16_t*)dst;
         for (size_t i = 0; i < HW; i++) o[i] = (int16_t)fminf(fmaxf(rintf(res[i]), -32768.f), 32767.f);
     } else {

@@ -340,6 +340,18 @@ static __device__ __forceinline__ float remap_finish(const RemapTaps& r)
     return r.v0 * w0 + r.v1 * w1 + r.v2 * w2 + r.v3 * w3;
 }
 
+// cv2.remap of a CV_8U image: remapBilinear<FixedPtCast<int, uchar, 15>, RemapVec_8u, short>: the weights are the float
+// table's entries x 2^15 as 16-bit integers -- for INTER_LINEAR the exact products (32 - ax)(32 - ay) 32 ... (the one entry
+// that does not fit a short, 32768 at ax = ay = 0, is stored as 32767 with the 1 moved to another tap: an 8-bit result cannot
+// tell) -- and the result is (sum + 2^14) >> 15.  Taps are 0..255 held as floats.
+static __device__ __forceinline__ float remap_finish_u8(const RemapTaps& r)
+{
+    const int w0 = (32 - r.ax) * (32 - r.ay) * 32, w1 = r.ax * (32 - r.ay) * 32, w2 = (32 - r.ax) * r.ay * 32, w3 = r.ax * r.ay * 32;
+    const int sum = (int)r.v0 * w0 + (int)r.v1 * w1 + (int)r.v2 * w2 + (int)r.v3 * w3;
+    const int v = (sum + (1 << 14)) >> 15;
+    return (float)(v < 0 ? 0 : v > 255 ? 255 : v);
+}
+
 // cv2.remap of a CV_64F image (remapBilinear<Cast<double, double>, ., float>): the float table weights widened, the four
 // products and three sums in double, no rounding to float.  pad: the image is the constant `padv` (a mean-pad slice).
 static __device__ __forceinline__ double remap_finish_f64(const RemapTaps& r, bool pad, double padv)
@@ -378,12 +390,13 @@ static __device__ __forceinline__ double remap_sample_f64(const double* __restri
 //   2  par on an integer MRC: the neighbour is an integer image: remap rounds half to even and saturates (lo, hi)
 template <int WM>
 static __device__ __forceinline__ float fold_warped(const float* __restrict__ src, int H, int W, int x, int y, float2 f, float acc_old,
-                                                    double weight, bool pad, double pad64, float lo, float hi)
+                                                    double weight, bool pad, double pad64, float lo, float hi, bool fixed8 = false)
 {
     RemapTaps r;
     remap_issue<false>(src, H, W, x, y, f, r);
     if (WM == 1) return (float)((double)acc_old + remap_finish_f64(r, pad, pad64) * weight);
-    if (WM == 2) return (float)((double)acc_old + (double)fminf(fmaxf(rintf(remap_finish(r)), lo), hi) * weight);
+    //   2  ... and a uint8 one (fixed8, wave-uniform): cv2.remap's 8-bit fixed point, an integer already
+    if (WM == 2) return (float)((double)acc_old + (double)(fixed8 ? remap_finish_u8(r) : fminf(fmaxf(rintf(remap_finish(r)), lo), hi)) * weight);
     return (float)((double)acc_old + (double)remap_finish(r) * weight);
 }
 

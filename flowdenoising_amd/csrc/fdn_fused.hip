@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
                             // (WM: the dtype semantics of an integer volume, fold_warped in fdn_device.h; the neighbour's stack index decides `pad`)
                             const int q = pb.t0 + b + pb.d;
                             const float acc_new = fold_warped<WM>(img1, H, W, xc, y, f, acc_old, weight, WM == 1 && (q < wm.pad_lo || q >= wm.pad_hi),
-                                                                  wm.pad64, wm.lo, wm.hi);
+                                                                  wm.pad64, wm.lo, wm.hi, wm.fixed8 != 0);
                             if (owner) {
                                 if (flow_out) st_off(flow_out, o * 8u, f);
                                 st_off(acc, o * 4u, acc_new);

@@ -61,7 +61,8 @@ void launch_update_flow(const float* Rstack, const float* Min, float* Mout, floa
 // 1 = the padded volume is float64 (seq on an integer MRC): remap weights in double, stack slices [0, pad_lo) and
 // [pad_hi, ...) hold the float64 value pad64; 2 = the neighbour is an integer image (par on an integer MRC): remap's
 // result is rounded half-to-even and saturated to [lo, hi].
-struct WarpMode { int kind = 0; int pad_lo = 0, pad_hi = 1 << 30; double pad64 = 0.; float lo = 0.f, hi = 0.f; };
+// fixed8 (with kind 2): the neighbour is a uint8 image: remap in OpenCV's 8-bit fixed point instead of float + rounding.
+struct WarpMode { int kind = 0; int pad_lo = 0, pad_hi = 1 << 30; double pad64 = 0.; float lo = 0.f, hi = 0.f; int fixed8 = 0; };
 void launch_sweep_side(const float* stack, const float* flows, float* acc, PairBatch pb, int nsteps, int first_step,
                        int H, int W, const double* weights, hipStream_t st, const WarpMode& wm = WarpMode());
 // acc[b] = f32( f64(acc[b]) + f64(stack[t0 + b + d]) * weight )   (centre tap, no-OF taps)
@@ -71,6 +72,8 @@ void launch_axpy_slices(const float* stack, float* acc, PairBatch pb, int H, int
 void launch_trunc_clamp(float* v, size_t count, float lo, float hi, hipStream_t st);
 // dst(y,x) = remap(src, flow)  single image (fdn_warp)
 void launch_warp(const float* src, const float* flow, float* dst, int H, int W, hipStream_t st);
+// the same for a CV_8U image (values 0..255 held as floats): cv2.remap's 8-bit fixed-point interpolation
+void launch_warp_u8(const float* src, const float* flow, float* dst, int H, int W, hipStream_t st);
 // the same for a CV_64F image: double in, double out (cv2.remap's Cast<double, double> path)
 void launch_warp_f64(const double* src, const float* flow, double* dst, int H, int W, hipStream_t st);
 

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(ACC ? 192 : 128) void k_farneback_iter(const float*
                 const float acc_old = ld_off<float>(acc, o * 4u);
                 const int q = pb.t0 + b + pb.d;        // (WM: integer-volume semantics, fold_warped in fdn_device.h)
                 const float acc_new = fold_warped<WM>(img1, H, W, xc, y, f, acc_old, weight, WM == 1 && (q < wm.pad_lo || q >= wm.pad_hi),
-                                                      wm.pad64, wm.lo, wm.hi);
+                                                      wm.pad64, wm.lo, wm.hi, wm.fixed8 != 0);
                 if (owner) st_off(acc, o * 4u, acc_new);
             }
             lds_barrier_iter();

@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void k_sweep_side(const float* __restrict__ st
                     const int q = pb.t0 + b + dir * (first_step + s0 + u + 1);
                     a = (float)((double)a + remap_finish_f64(t[u], q < wm.pad_lo || q >= wm.pad_hi, wm.pad64) * sw.w[s0 + u]);
                 } else if (MODE == 2) {   // integer neighbour image (par on integer input): saturate_cast<T>(float) = cvRound, clamped
-                    const float v = fminf(fmaxf(rintf(remap_finish(t[u])), wm.lo), wm.hi);
+                    const float v = wm.fixed8 ? remap_finish_u8(t[u]) : fminf(fmaxf(rintf(remap_finish(t[u])), wm.lo), wm.hi);
                     a = (float)((double)a + (double)v * sw.w[s0 + u]);
                 } else
                     a = (float)((double)a + (double)remap_finish(t[u]) * sw.w[s0 + u]);
@@ -561,6 +561,23 @@ void launch_warp(const float* src, const float* flow, float* dst, int H, int W, 
 {
     dim3 grid((W + 63) / 64, (H + 3) / 4, 1);
     hipLaunchKernelGGL(k_warp, grid, dim3(256), 0, st, src, flow, dst, H, W);
+}
+
+__global__ __launch_bounds__(256) void k_warp_u8(const float* __restrict__ src, const float* __restrict__ flow_base,
+                                                 float* __restrict__ dst, int H, int W)
+{
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    size_t o = (size_t)y * W + x;
+    RemapTaps r;
+    remap_issue<false>(src, H, W, x, y, ((const float2*)flow_base)[o], r);
+    dst[o] = remap_finish_u8(r);
+}
+void launch_warp_u8(const float* src, const float* flow, float* dst, int H, int W, hipStream_t st)
+{
+    dim3 grid((W + 63) / 64, (H + 3) / 4, 1);
+    hipLaunchKernelGGL(k_warp_u8, grid, dim3(256), 0, st, src, flow, dst, H, W);
 }
 
 __global__ __launch_bounds__(256) void k_warp_f64(const double* __restrict__ src, const float* __restrict__ flow_base,

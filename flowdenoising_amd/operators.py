@@ -114,8 +114,8 @@ def integer_semantics(vol, params, mean_on_device=False):
       mean-padded (seq): vol.mean() is a float64, hence a float64 padded volume (seq:88-89): cv2.remap weights in
         double, the pad slices hold the float64 mean;
       wrap-around (par): neighbour slices are integer images: cv2.remap rounds and saturates, each pass is truncated
-        into the integer volume (par:131, 287-289).  cv2.remap has no CV_8S path (the reference raises there) and its
-        CV_8U path interpolates in fixed point, which is not restated here."""
+        into the integer volume (par:131, 287-289).  cv2.remap has no CV_8S path (the reference raises there); its
+        CV_8U path interpolates in 8-bit fixed point (FDN_WARP_FIXED_U8)."""
     vol = np.asarray(vol)
     if not np.issubdtype(vol.dtype, np.integer):
         return params
@@ -131,10 +131,9 @@ def integer_semantics(vol, params, mean_on_device=False):
     else:
         if params.use_of and vol.dtype == np.int8:
             raise ValueError("cv2.remap does not accept 8-bit signed images (the reference fails on a mode-0 MRC here)")
-        if params.use_of and vol.dtype == np.uint8:
-            raise NotImplementedError("cv2.remap interpolates 8-bit unsigned images in fixed point; that path is not restated")
         info = np.iinfo(vol.dtype)
-        p.warp_mode = _lib.WARP_ROUND_INT
+        # uint8 images are interpolated in 8-bit fixed point by cv2.remap (FDN_WARP_FIXED_U8); 16-bit ones in float, then rounded
+        p.warp_mode = _lib.WARP_FIXED_U8 if vol.dtype == np.uint8 else _lib.WARP_ROUND_INT
         p.round_lo, p.round_hi = float(info.min), float(info.max)
     return p
 

@@ -68,6 +68,8 @@ typedef struct fdn_sweep_params {
 #define FDN_WARP_F32 0
 #define FDN_WARP_F64_PADDED 1
 #define FDN_WARP_ROUND_INT 2
+#define FDN_WARP_FIXED_U8 3   /* par on a uint8 volume: cv2.remap interpolates 8-bit images in fixed point (16-bit integer weights
+                                 = table weights x 2^15, (sum + 2^14) >> 15); every pass truncated into [0, 255] (par:131, 287-289) */
 
 /* ---- lifetime ------------------------------------------------------------------ */
 /* Binds a handle to HIP device `device` and creates its stream.  Replaces the implicit
@@ -171,8 +173,8 @@ int fdn_warp_dev(fdn_handle h, const float* d_reference, ptrdiff_t row_stride, p
  * The reference hands cv2 whatever its arrays are: slices of an integer MRC (par:312, dtype of the file) or of the
  * float64 padded volume seq:88-89 builds from one.  cv2.calcOpticalFlowFarneback converts both images to float32
  * (convertTo(CV_32F)); cv2.remap computes per depth and returns the image's type: CV_64F weights in double without
- * rounding to float, CV_16S / CV_16U in float and then rounds half to even and saturates; CV_8S is not supported by
- * cv2.remap (error here too) and CV_8U (fixed-point interpolation) is not restated (error).  HOST pointers; strides
+ * rounding to float, CV_16S / CV_16U in float and then rounds half to even and saturates; CV_8U in fixed point (16-bit integer
+ * weights, (sum + 2^14) >> 15); CV_8S is not supported by cv2.remap (error here too).  HOST pointers; strides
  * in elements of the image's type; flow (H x W x 2 float32) and dst (H x W, the reference's type) contiguous. */
 #define FDN_DEPTH_F32 0
 #define FDN_DEPTH_F64 1

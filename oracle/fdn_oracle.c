@@ -866,6 +866,58 @@ FDO_EXPORT void fdo_remap_linear_replicate(const float* src, int H, int W, const
         }
 }
 
+/* cv2.remap of a CV_8U image (a slice of a uint8 volume in par, src/flowdenoising.py:312): OpenCV interpolates 8-bit
+ * images in FIXED POINT -- remapBilinear<FixedPtCast<int, uchar, INTER_REMAP_COEF_BITS = 15>, RemapVec_8u, short>: the four
+ * weights are the float table entries times 32768 as 16-bit integers (for INTER_LINEAR the products (32 - ax)(32 - ay) 32,
+ * ... are exact integers that sum to 32768; the one entry that does not fit a short, 32768 at ax = ay = 0, is stored as
+ * 32767 with the missing 1 given to another tap by initInterTab2D's fix-up -- which cannot change an 8-bit result: the
+ * other tap differs from this one by at most 255 << 16384), the sum is an int and the result (sum + 2^14) >> 15.
+ * Same 1/32-pixel coordinates and BORDER_REPLICATE clamping as the float path.  Values 0..255 held in floats. */
+static float remap_u8_fixed_point(float v0, float v1, float v2, float v3, int ax, int ay)
+{
+    const int w0 = (32 - ax) * (32 - ay) * 32, w1 = ax * (32 - ay) * 32, w2 = (32 - ax) * ay * 32, w3 = ax * ay * 32;
+    const int sum = (int)v0 * w0 + (int)v1 * w1 + (int)v2 * w2 + (int)v3 * w3;
+    int r = (sum + (1 << 14)) >> 15;
+    r = r < 0 ? 0 : r > 255 ? 255 : r;      /* saturate_cast<uchar> (a convex combination: never taken) */
+    return (float)r;
+}
+static void remap_u8_image(const float* src, int H, int W, const float* mapxy, float* dst)
+{
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const float* mp = mapxy + ((size_t)y * W + x) * 2;
+            int sx = cv_round_f(mp[0] * 32), sy = cv_round_f(mp[1] * 32);
+            int ax = sx & 31, ay = sy & 31;
+            int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);
+            int x0 = clampi(ix, 0, W - 1), x1 = clampi(ix + 1, 0, W - 1);
+            int y0 = clampi(iy, 0, H - 1), y1 = clampi(iy + 1, 0, H - 1);
+            dst[(size_t)y * W + x] = remap_u8_fixed_point(src[(size_t)y0 * W + x0], src[(size_t)y0 * W + x1],
+                                                          src[(size_t)y1 * W + x0], src[(size_t)y1 * W + x1], ax, ay);
+        }
+}
+FDO_EXPORT void fdo_remap_linear_replicate_u8(const unsigned char* src, int H, int W, const float* mapxy, unsigned char* dst)
+{
+    const size_t n = (size_t)H * W;
+    float* f = (float*)malloc(n * sizeof(float));
+    float* g = (float*)malloc(n * sizeof(float));
+    for (size_t i = 0; i < n; i++) f[i] = (float)src[i];
+    remap_u8_image(f, H, W, mapxy, g);
+    for (size_t i = 0; i < n; i++) dst[i] = (unsigned char)g[i];
+    free(f); free(g);
+}
+static void warp_slice_u8(const float* reference, const float* flow, float* dst, int H, int W)
+{
+    float* map = (float*)malloc((size_t)H * W * 2 * sizeof(float));
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            size_t i = ((size_t)y * W + x) * 2;
+            map[i] = (float)((double)flow[i] + (double)x);
+            map[i + 1] = (float)((double)flow[i + 1] + (double)y);
+        }
+    remap_u8_image(reference, H, W, map, dst);
+    free(map);
+}
+
 FDO_EXPORT void fdo_warp_slice(const float* reference, const float* flow, float* dst, int H, int W)
 {
     float* map = (float*)malloc((size_t)H * W * 2 * sizeof(float));
@@ -935,7 +987,7 @@ FDO_EXPORT void fdo_set_f64_padded(int on, double mean64) { g_f64_padded = on; g
 /* par on an integer MRC (par:472 keeps the dtype): the neighbour slices are integer images, so cv2.remap returns that type:
  * remapBilinear<Cast<float, short>> = saturate_cast<short>(float) = cvRound (half to even), clamped to the type's range;
  * and self.filtered_vol = np.zeros_like(vol) truncates every pass's float32 slices toward zero (par:131, par:287-289). */
-static int g_int_round = 0;
+static int g_int_round = 0;       /* 1: 16-bit images (float interpolation, rounded and saturated); 2: uint8 images (fixed point) */
 static float g_int_lo = 0.f, g_int_hi = 0.f;
 FDO_EXPORT void fdo_set_int_round(int on, double lo, double hi) { g_int_round = on; g_int_lo = (float)lo; g_int_hi = (float)hi; }
 
@@ -1039,8 +1091,9 @@ FDO_EXPORT void fdo_filter_axis_range(const float* vol, float* out, int Z, int Y
                         for (size_t j = 0; j < npx; j++) tmp[j] = (float)((double)tmp[j] + warped64[j] * kernel[i]);
                         continue;
                     }
-                    fdo_warp_slice(ref, flow, warped, H, W);       /* seq:106 */
-                    if (g_int_round)
+                    if (g_int_round == 2) warp_slice_u8(ref, flow, warped, H, W);   /* a uint8 neighbour image: fixed-point remap, already integral */
+                    else fdo_warp_slice(ref, flow, warped, H, W);       /* seq:106 */
+                    if (g_int_round == 1)
                         for (size_t j = 0; j < npx; j++) {
                             float v = rintf(warped[j]);
                             warped[j] = v < g_int_lo ? g_int_lo : v > g_int_hi ? g_int_hi : v;

@@ -86,9 +86,9 @@ def filter_par_integer_input(vol, kernel, l, w, nthreads=1, use_of=True, chained
     cv2.remap rounds half to even and saturates -- and every pass truncated into the integer volume (fdn_oracle.c,
     fdo_set_int_round).  Returns float32 holding the integer values (all three passes; the reference loses its X pass)."""
     vol = np.asarray(vol)
-    assert vol.dtype in (np.int16, np.uint16) or (not use_of and np.issubdtype(vol.dtype, np.integer))
+    assert vol.dtype in (np.int16, np.uint16, np.uint8) or (not use_of and np.issubdtype(vol.dtype, np.integer))
     info = np.iinfo(vol.dtype)
-    lib().fdo_set_int_round(ctypes.c_int(1), ctypes.c_double(info.min), ctypes.c_double(info.max))
+    lib().fdo_set_int_round(ctypes.c_int(2 if vol.dtype == np.uint8 else 1), ctypes.c_double(info.min), ctypes.c_double(info.max))
     try:
         return _filter_3d(vol.astype(np.float32), kernel, l, w, use_of, 1, chained, BOX_RUNNING, nthreads, mean=np.float32(0))
     finally:
@@ -151,7 +151,7 @@ def remap(src, map_xy):
 def remap_any(src, map_xy):
     """cv2.remap(src, map, None, INTER_LINEAR, BORDER_REPLICATE) for the image depths the reference can meet: float32;
     float64 (remapBilinear<Cast<double, double>>: weights widened, arithmetic in double); int16 / uint16 (Cast<float, T>:
-    float arithmetic, then saturate_cast = round half to even, clamped).  Returns an array of src's dtype, like cv2."""
+    float arithmetic, then saturate_cast = round half to even, clamped); uint8 (fixed point, FixedPtCast<int, uchar, 15>).  Returns an array of src's dtype, like cv2."""
     src = np.asarray(src)
     map_xy = _f32(map_xy)
     H, W = src.shape
@@ -163,6 +163,11 @@ def remap_any(src, map_xy):
     if src.dtype in (np.int16, np.uint16):
         info = np.iinfo(src.dtype)
         return np.clip(np.rint(remap(src.astype(np.float32), map_xy)), info.min, info.max).astype(src.dtype)
+    if src.dtype == np.uint8:       # FixedPtCast<int, uchar, 15>: 16-bit integer weights, (sum + 2^14) >> 15
+        s8 = np.ascontiguousarray(src)
+        dst = np.empty((H, W), np.uint8)
+        lib().fdo_remap_linear_replicate_u8(_p(s8), ctypes.c_int(H), ctypes.c_int(W), _p(map_xy), _p(dst))
+        return dst
     if src.dtype != np.float32:
         raise TypeError(f"cv2.remap: unsupported depth {src.dtype} in this restatement")
     return remap(src, map_xy)

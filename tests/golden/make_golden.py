@@ -105,6 +105,9 @@ def volume(shape, seed, dtype=np.float32):
     sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
     from flowdenoising_amd.synth import make_volume
     v = make_volume(shape, seed=seed, amplitude=100.0)
+    if dtype == np.uint8:
+        lo, hi = float(v.min()), float(v.max())
+        return np.round((v - lo) / (hi - lo) * 255).astype(np.uint8)
     if np.issubdtype(dtype, np.integer):
         lo, hi = float(v.min()), float(v.max())
         return (np.round((v - lo) / (hi - lo) * 4095) - 1000).astype(dtype)
@@ -162,6 +165,11 @@ def sweeps():
     zy, zyx = run_par(vpi.copy(), 0, 5, par.get_flow_with_prev_flow)
     assert zy.dtype == np.int16 and zyx.dtype == np.int16      # par:131: results live in arrays of the input's dtype
     save("ref_sweep_par_i16_l0_w5.npz", vol=vpi, sigmas=np.array(sig), l=np.array(0), w=np.array(5), chained=np.array(1), out_zy=zy, out_zyx=zyx)
+    # a uint8 volume: cv2.remap interpolates 8-bit images in fixed point (the oracle's remap_any restates FixedPtCast<int, uchar, 15>)
+    vpu = volume((12, 40, 48), 106, np.uint8)
+    zy, zyx = run_par(vpu.copy(), 0, 5, par.get_flow_with_prev_flow)
+    assert zy.dtype == np.uint8 and zyx.dtype == np.uint8
+    save("ref_sweep_par_u8_l0_w5.npz", vol=vpu, sigmas=np.array(sig), l=np.array(0), w=np.array(5), chained=np.array(1), out_zy=zy, out_zyx=zyx)
 
 
 def main():

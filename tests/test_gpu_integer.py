@@ -113,6 +113,27 @@ def test_par_semantics_integer_images(fdn, oracle, dtype, shift, l, w, chained):
     assert np.array_equal(want, np.trunc(want))            # integers all along
 
 
+@pytest.mark.parametrize("l,w,path", [(0, 5, 0), (0, 5, 1), (2, 15, 0), (0, 7, 2)])
+def test_par_semantics_uint8_fixed_point_remap(fdn, oracle, l, w, path):
+    """A uint8 volume in par: cv2.remap interpolates 8-bit images in fixed point (FDN_WARP_FIXED_U8; oracle.remap_any restates
+    FixedPtCast<int, uchar, 15>) -- on the 3-iteration kernel, the per-stage kernels and the one-iteration kernel."""
+    from flowdenoising_amd.operators import handle
+    vol = (_int_vol((8, 44, 52), 25, np.int16, 0) // 17).astype(np.uint8)
+    ks = [fdn.get_gaussian_kernel(s) for s in (1.0, 0.5, 1.0)]
+    want = oracle.filter_par_integer_input(vol, ks, l, w, nthreads=8)
+    as16 = oracle.filter_par_integer_input(vol.astype(np.uint16), ks, l, w, nthreads=8)     # float interpolation, then rounding
+    assert not np.array_equal(want, np.clip(as16, 0, 255))                                  # ... is NOT what cv2 does to 8-bit images
+    h = handle()
+    h.set_option("path", path)
+    try:
+        v = vol.copy()
+        fd = fdn.FlowDenoising(4, v, l, w, fdn.get_flow_with_prev_flow, fdn.warp_slice)
+        assert fd.filter(ks) is None
+    finally:
+        h.set_option("path", 0)
+    assert v.dtype == np.uint8 and np.array_equal(v, want.astype(np.uint8))
+
+
 def test_par_semantics_no_of_and_unsupported_types(fdn, oracle):
     vol = _int_vol((8, 30, 34), 16, np.int16, 100)
     ks = [fdn.get_gaussian_kernel(0.5)] * 3
@@ -173,6 +194,7 @@ def test_pair_operators_on_the_reference_s_own_dtypes(fdn, oracle):
     padded[2:11] = vol
     for ref, tgt in ((vol[:, 7, :], vol[:, 8, :]),                                  # par: int16 views (row-strided)
                      (vol.astype(np.uint16)[:, :, 5], vol.astype(np.uint16)[:, :, 6]),   # element-strided uint16
+                     (((vol - vol.min()) // 5).astype(np.uint8)[:, 11, :], ((vol - vol.min()) // 5).astype(np.uint8)[:, 12, :]),   # par on a uint8 volume: fixed-point remap
                      (padded[:, :, 9], vol[:, :, 9]),                               # seq: float64 reference, int16 target
                      (padded[1], padded[2])):                                       # a pad slice (constant float64 mean)
         H, W = ref.shape

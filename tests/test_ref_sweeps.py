@@ -27,7 +27,7 @@ def load(name):
 
 def test_fixture_set_is_complete():
     names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLD, "ref_sweep_*.npz")))
-    assert names == ["ref_sweep_par_f32_l0_w5.npz", "ref_sweep_par_f32_l0_w5_recompute.npz", "ref_sweep_par_i16_l0_w5.npz",
+    assert names == ["ref_sweep_par_f32_l0_w5.npz", "ref_sweep_par_f32_l0_w5_recompute.npz", "ref_sweep_par_i16_l0_w5.npz", "ref_sweep_par_u8_l0_w5.npz",
                      "ref_sweep_seq_alongZ_f32_l1_w7.npz", "ref_sweep_seq_f32_l0_w5.npz", "ref_sweep_seq_f32_l1_w7.npz",
                      "ref_sweep_seq_i16_l0_w5.npz"]
     for n in names:                                   # the outputs are not trivial copies of the inputs
@@ -67,10 +67,12 @@ def test_oracle_wrap_sweeps_equal_par_control_flow(oracle, name):
     assert np.array_equal(oracle.OF_filter(g["vol"], [ks[0], ks[1], None], 0, 5, border_mode=1, chained=chained), g["out_zy"])
 
 
-def test_oracle_integer_wrap_sweeps_equal_par_control_flow(oracle):
-    g = load("ref_sweep_par_i16_l0_w5.npz")
+@pytest.mark.parametrize("name,dtype", [("ref_sweep_par_i16_l0_w5.npz", np.int16), ("ref_sweep_par_u8_l0_w5.npz", np.uint8)])
+def test_oracle_integer_wrap_sweeps_equal_par_control_flow(oracle, name, dtype):
+    """int16: cv2.remap in float, rounded and saturated; uint8: cv2.remap's 8-bit fixed point (oracle.remap_any)."""
+    g = load(name)
     ks = [oracle.get_gaussian_kernel(float(s)) for s in g["sigmas"]]
-    assert g["out_zyx"].dtype == np.int16
+    assert g["out_zyx"].dtype == dtype
     assert np.array_equal(oracle.filter_par_integer_input(g["vol"], ks, 0, 5), g["out_zyx"].astype(np.float32))
     assert np.array_equal(oracle.filter_par_integer_input(g["vol"], [ks[0], ks[1], None], 0, 5), g["out_zy"].astype(np.float32))
 
@@ -93,7 +95,7 @@ def test_hip_along_Z_with_a_pyramid_level_equals_seq_control_flow(fdn):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["ref_sweep_par_f32_l0_w5.npz", "ref_sweep_par_f32_l0_w5_recompute.npz", "ref_sweep_par_i16_l0_w5.npz"])
+@pytest.mark.parametrize("name", ["ref_sweep_par_f32_l0_w5.npz", "ref_sweep_par_f32_l0_w5_recompute.npz", "ref_sweep_par_i16_l0_w5.npz", "ref_sweep_par_u8_l0_w5.npz"])
 def test_hip_FlowDenoising_equals_par_control_flow(fdn, name):
     """The class of flowdenoising.py, same constructor and filter(kernels): with all three kernels `vol` holds the full
     Z -> Y -> X result (= par's filtered_vol; the documented deviation from par's lost X pass), with [kz, ky, None] what
