@@ -194,7 +194,25 @@ def test_sweep_params_layout_matches_the_header(tmp_path):
     got = [int(v) for v in subprocess.check_output([str(tmp_path / "l")]).split()]
     assert got[0] == ctypes.sizeof(_lib.SweepParams)
     assert got[1:] == [getattr(_lib.SweepParams, n).offset for n in names]
-    assert (_lib.WARP_F32, _lib.WARP_F64_PADDED, _lib.WARP_ROUND_INT) == (0, 1, 2)
+    assert (_lib.WARP_F32, _lib.WARP_F64_PADDED, _lib.WARP_ROUND_INT, _lib.WARP_FIXED_U8) == (0, 1, 2, 3)
+
+
+def test_transport_header_is_c_and_its_structs_match_ctypes(tmp_path):
+    """include/flowdn_rccl.h compiles as plain C99 (a C caller includes it) and fdn_msg / fdn_comm have the layout the ctypes
+    layer assumes."""
+    import ctypes
+    import subprocess
+    from flowdenoising_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "flowdn_rccl.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %d %d %d", '
+           'sizeof(fdn_msg), offsetof(fdn_msg, bytes), offsetof(fdn_msg, peer), offsetof(fdn_msg, is_send), sizeof(fdn_comm), '
+           'offsetof(fdn_comm, exchange), offsetof(fdn_comm, allgather_host), FDN_TRANSPORT_RCCL, FDN_TRANSPORT_SHM, FDN_TRANSPORT_NULL); return 0; }\n')
+    (tmp_path / "t.c").write_text(src)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-I", os.path.join(root, "include"), "-o", str(tmp_path / "t"), str(tmp_path / "t.c")])
+    got = [int(v) for v in subprocess.check_output([str(tmp_path / "t")]).split()]
+    assert got[:4] == [ctypes.sizeof(_lib.FdnMsg), _lib.FdnMsg.bytes.offset, _lib.FdnMsg.peer.offset, _lib.FdnMsg.is_send.offset]
+    assert got[4:7] == [ctypes.sizeof(_lib.FdnComm), _lib.FdnComm.exchange.offset, _lib.FdnComm.allgather_host.offset]
+    assert got[7:] == [_lib.TRANSPORT_RCCL, _lib.TRANSPORT_SHM, _lib.TRANSPORT_NULL]
 
 
 def test_tiff_deflate_pages_and_predictor(tmp_path):
