@@ -57,7 +57,9 @@ typedef struct fdn_sweep_params {
      *     pad slices hold the float64 mean `pad64` (Farneback still sees float32 images: pad_value = (float)pad64);
      *   FDN_WARP_ROUND_INT (par): the neighbour slices ARE integer images: cv2.remap's result is rounded half to
      *     even and saturated to the type's range [round_lo, round_hi], and every pass's result is truncated toward
-     *     zero into the integer volume (par:131, par:287-289).
+     *     zero into the integer volume (par:131, par:287-289);
+     *   FDN_WARP_FIXED_U8 (par, uint8 volume): the same, except that cv2.remap interpolates 8-bit images in fixed point
+     *     (16-bit integer weights, (sum + 2^14) >> 15); range [0, 255].
      * The caller converts the volume to float32 (exact for 8/16-bit types) and says which it was. */
     int warp_mode;   /* FDN_WARP_*                                              */
     int pad_lo, pad_hi; /* fdn_sweep_stack_dev with FDN_WARP_F64_PADDED: how many leading / trailing stack slices are
