@@ -7,7 +7,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/flowdenoising_amd/csrc
 obj=/tmp/fdn_variant_$name
 mkdir -p $obj $root/build_variants
-FLAGS="-O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-function -I$src -I$root/include $extra"
+FLAGS="-O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off --offload-arch=${ARCH:-gfx950} -Wall -Wno-unused-function -I$src -I$root/include $extra"
 for f in fdn_api fdn_kernels fdn_iter; do
   # only the fused / iter kernels take experiment switches: reuse the product objects for the rest when they are current
   if [ "$f" != fdn_iter ] && [ -f $src/obj/$f.o ] && [ $src/obj/$f.o -nt $src/$f.hip ]; then cp $src/obj/$f.o $obj/$f.o; else /opt/rocm/bin/hipcc $FLAGS -c -o $obj/$f.o $src/$f.hip & fi
