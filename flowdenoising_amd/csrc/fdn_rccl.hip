@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cerrno>
 #include <cstdarg>
