@@ -1,4 +1,4 @@
-"""Randomised parity campaign for integer volumes: int16 / uint16 volumes through the three-pass
+"""Randomised parity campaign for integer volumes: int16 / uint16 / uint8 volumes through the three-pass
 filter with seq's semantics (float64 padded volume) and par's (integer images), random shapes, sigmas, levels and windows,
 GPU against the oracle's restatements, bit for bit.
 usage: random_campaign_int.py [n] [seed]"""
@@ -13,8 +13,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 31)
 bad = 0
 for i in range(n):
     shape = (int(rng.integers(5, 14)), int(rng.integers(33, 150)), int(rng.integers(33, 150)))
-    dtype = [np.int16, np.uint16][int(rng.integers(2))]
-    span = int(rng.choice([255, 4095, 30000]))
+    dtype = [np.int16, np.uint16, np.uint8][int(rng.integers(3))]       # uint8 (round 4): par's fixed-point remap, seq's float64 padding
+    span = 255 if dtype == np.uint8 else int(rng.choice([255, 4095, 30000]))
     v = make_volume(shape, seed=int(rng.integers(1 << 30)), amplitude=100.0)
     lo, hi = float(v.min()), float(v.max())
     vi = np.round((v - lo) / (hi - lo) * span)
