@@ -267,31 +267,46 @@ def cpu_baseline(vol_t, shape, kernel, mean, n_targets, levels, winsize):
                       "reference itself would be slower than this"}
 
 
+def relay_json(line):
+    """Only the JSON line goes to stdout (gloo, the rehearsal backend, prints its connection banner there too)."""
+    out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+    out.write(line)
+    out.flush()
+
+
+def run_torch_distributed(a, extra_env=None):
+    """N ranks of the torch.distributed slab engine (--engine python) as children of this process: torch.distributed.run."""
+    port = int(os.environ.get("MASTER_PORT", 0)) or 29500 + os.getpid() % 2000
+    args = [v for v in sys.argv[1:] if v not in ("--engine", "native", "python")] + ["--engine", "python"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + args
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "2")
+    env.update(extra_env or {})
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    for line in proc.stdout:       # stderr goes straight through
+        relay_json(line)
+    return proc.wait()
+
+
 def self_launch(a):
     """`python bench.py --gpus N` from a bare shell (how the driver calls it): start the N ranks as CHILD processes --
     before anything here imports torch or touches the GPU, and never by exec --, relay rank 0's JSON line and return
     the first non-zero exit code.  native engine: plain subprocess.Popen ranks that meet through libflowdn_rccl.so
-    (flowdenoising_amd/launch.py); python engine: torch.distributed.run, as that engine needs a process group."""
-    if a.engine == "native":
-        from flowdenoising_amd import launch
-
-        def relay(line):               # only the JSON line goes to stdout
-            out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
-            out.write(line)
-            out.flush()
-        return launch.spawn([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], a.gpus, relay=relay)
-    port = int(os.environ.get("MASTER_PORT", 0)) or 29500 + os.getpid() % 2000
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this host driver
-    env.setdefault("OMP_NUM_THREADS", "2")
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
-    for line in proc.stdout:       # stderr goes straight through.  Only the JSON line is relayed on stdout: gloo (the rehearsal
-        out = sys.stdout if line.lstrip().startswith("{") else sys.stderr     # backend) prints its connection banner to stdout
-        out.write(line)
-        out.flush()
-    return proc.wait()
+    (flowdenoising_amd/launch.py); python engine: torch.distributed.run, as that engine needs a process group.
+    If the native job fails, this parent -- which has never touched a GPU -- starts N FRESH children once more on the
+    torch.distributed engine, and the line they print says so (`transport_fallback`)."""
+    if a.engine != "native":
+        return run_torch_distributed(a)
+    from flowdenoising_amd import launch
+    errors = []
+    rc = launch.spawn([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], a.gpus, relay=relay_json, errors=errors)
+    if rc == 0 or os.environ.get("FDN_BENCH_NO_FALLBACK") == "1":
+        return rc
+    why = f"native job failed (exit code {rc}" + ("; " + " | ".join(errors) if errors else "") + ")"
+    print(f"bench.py: WARNING: {why}; starting {a.gpus} fresh ranks on the torch.distributed slab engine", file=sys.stderr)
+    return run_torch_distributed(a, {"FDN_BENCH_FALLBACK": why[:1500]})
 
 
 def workload_names(shape, sig3, axes, levels, winsize):
@@ -315,24 +330,25 @@ def workload_names(shape, sig3, axes, levels, winsize):
     return metric, (f"BASELINE.json configs[{cfg}]" if cfg is not None else "not one of BASELINE.json's configs")
 
 
-def check_sharded(h, tr, dev, rank, world, shape, kernels, params, amplitude, slab_out, levels):
-    """After the timed region of an N > 1 run: every rank sends its output slab to rank 0 (native transport), which
-    regenerates the whole synthetic volume, filters it on its own GPU alone (fdn_filter_3d_dev), requires the gathered
-    sharded output to equal that single-GPU output bit for bit, and has the oracle recompute one target slice per pass
-    (check_output).  Returns the block on rank 0, None elsewhere."""
+def check_sharded(h, move, dev, rank, world, shape, kernels, params, amplitude, slab_out, levels):
+    """After the timed region of an N > 1 run: every rank sends its output slab to rank 0, which regenerates the whole
+    synthetic volume, filters it on its own GPU alone (fdn_filter_3d_dev), requires the gathered sharded output to equal
+    that single-GPU output bit for bit, and has the oracle recompute one target slice per pass (check_output).
+    move: (send_to_0(tensor), recv_from(rank, tensor), barrier) of the engine in use.  Returns the block on rank 0."""
     import torch
     from flowdenoising_amd import distributed as fd, synth
+    send_to_0, recv_from, barrier = move
     Z, Y, X = shape
     parts = fd.split(Z, world)
     torch.cuda.synchronize()
     if rank != 0:
-        tr.exchange([(slab_out.data_ptr(), slab_out.numel() * 4, 0, True)], 0)
+        send_to_0(slab_out)
         torch.cuda.synchronize()
-        tr.barrier()                      # rank 0's single-GPU rerun and oracle check happen behind this barrier
+        barrier()                         # rank 0's single-GPU rerun and oracle check happen behind this barrier
         return None
     full = torch.empty(shape, dtype=torch.float32, device=dev)
     full[parts[0][0]:parts[0][1]].copy_(slab_out)
-    tr.exchange([(full[z0:z1].data_ptr(), (z1 - z0) * Y * X * 4, r, False) for r, (z0, z1) in enumerate(parts) if r != 0], 0)
+    recv_from([(r, full[z0:z1]) for r, (z0, z1) in enumerate(parts) if r != 0])
     torch.cuda.synchronize()
     # the volume the ranks filtered: the generator seeds a slab's noise by its first slice, so the whole is their concatenation
     vol = torch.cat([synth.make_volume(shape, seed=1234 + 3, amplitude=amplitude, xp=torch, device=dev, z0=z0, zlen=z1 - z0) for z0, z1 in parts])
@@ -347,46 +363,93 @@ def check_sharded(h, tr, dev, rank, world, shape, kernels, params, amplitude, sl
     res["ok"] = bool(res["ok"] and same)
     res["how"] = (f"the {world} ranks' output slabs gathered on rank 0 and compared with a single-GPU fdn_filter_3d_dev of the same "
                   "synthetic volume (bit for bit); that single-GPU output then checked as at N = 1: " + res["how"])
-    tr.barrier()
+    barrier()
     return res
 
 
 def main():
     a = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before torch or any HIP library is loaded: both launch routes alike
     from flowdenoising_amd import launch
     job = launch.job()
     if a.gpus > 1 and job is None:
         sys.exit(self_launch(a))
+    fallback = os.environ.get("FDN_BENCH_FALLBACK") or None
+    if job is not None and a.engine == "native" and launch.started_by_torchrun():
+        # A rank torch.distributed.run started (the round driver's N > 1 launch).  It has not touched a GPU: the native
+        # job's rank runs in ONE child of this process; if the native job fails anywhere, every rank gets here with a
+        # reason, still fresh, and carries the run on the torch.distributed engine instead (said so in the line).
+        rc, why = launch.supervise_rank([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], job, relay=relay_json)
+        if rc == 0:
+            if job[0] == 0:
+                launch.remove_derived_rendezvous(job[3])
+            sys.exit(0)
+        if os.environ.get("FDN_BENCH_NO_FALLBACK") == "1":
+            sys.exit(rc or 1)
+        fallback = ("native job failed (" + " | ".join(why) + ")")[:1500]
+        if job[0] == 0:
+            print(f"bench.py: WARNING: {fallback}; the ranks go on with the torch.distributed slab engine", file=sys.stderr)
+        a.engine = "python"
+    try:
+        run(a, job, fallback)
+    except BaseException as e:      # noqa: BLE001 -- a rank that cannot go on says why, tells the others, and leaves at once
+        if isinstance(e, SystemExit) and not e.code:
+            raise
+        if job is None:
+            raise
+        import traceback
+        traceback.print_exc()
+        launch.report_failure(job[3], job[0], f"{type(e).__name__}: {e}")
+        tr = _live.get("tr")
+        if tr is not None:
+            tr.abort()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(1)                 # no destructors: a communicator whose peers are gone may never come back from its teardown
+
+
+_live = {}                          # the rank's transport, for the failure path above
+
+
+def run(a, job, fallback):
     import torch
-    from flowdenoising_amd import _lib, synth
+    from flowdenoising_amd import _lib, launch, synth
 
     rank, world, local_rank, rdv = job if job is not None else (0, 1, 0, None)
     if world != a.gpus:          # started by torch.distributed.run with another rank count: the environment decides
         a.gpus = world
     ngpu = torch.cuda.device_count()
-    rehearsal = world > 1 and ngpu < world    # fewer GPUs than ranks (a one-GPU box): the ranks share GPUs and exchange through
-    tr = dist = None                          # host memory -- exercises every line of the N > 1 path, its numbers mean nothing
-    fallback = None
+    tr = dist = None
     if world > 1 and a.engine == "native":
-        try:
-            tr, device = launch.make_transport(rank, world, local_rank, rdv)      # RCCL, or shared memory when ranks share a GPU
-        except Exception as e:      # e.g. the native library cannot be loaded on this node: under torch.distributed.run the
-            if "MASTER_PORT" not in os.environ:      # torch.distributed engine can still carry the run (said so in the line)
-                raise
-            fallback = f"native transport unavailable ({type(e).__name__}: {e}); torch.distributed slab engine used instead"
-            print("bench.py: WARNING: " + fallback, file=sys.stderr)
-            a.engine = "python"
-    if tr is None:
+        tr, device = launch.make_transport(rank, world, local_rank, rdv)      # RCCL, or shared memory when ranks share a GPU
+        _live["tr"] = tr
+        if os.environ.get("FDN_TEST_FAIL_NATIVE") == str(rank):               # tests: this native rank gives up here
+            raise RuntimeError("FDN_TEST_FAIL_NATIVE: injected failure of the native engine")
+    else:
         device = local_rank % max(ngpu, 1)
     torch.cuda.set_device(device)
     dev = torch.device("cuda", device)
-    if world > 1 and a.engine == "python":
+    devices = None
+    if tr is not None:
+        n_seen, devices = tr.count(), tr.devices()
+    elif world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo")
+        # which GPUs the ranks really sit on decides the backend: gloo + host staging when they share one (a rehearsal)
+        sub = os.path.join(rdv, "py_engine")
+        os.makedirs(sub, mode=0o700, exist_ok=True)
+        devices = launch._exchange_lines(sub, rank, world, _lib.device_pci_id(device))
+        limit = datetime.timedelta(seconds=float(os.environ.get("FDN_RDV_TIMEOUT", "300")))
+        if len(set(devices)) < world:
+            dist.init_process_group("gloo", timeout=limit)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
+        n_seen = dist.get_world_size()
+    else:
+        n_seen = 1
+    rehearsal = world > 1 and len(set(devices)) < world     # ranks share GPUs (a one-GPU box): every line of the N > 1 path runs,
+                                                            # exchanges go through host memory, and no number of it means anything
 
     shape = tuple(int(v) for v in a.shape.split(","))
     Z, Y, X = shape
@@ -442,11 +505,13 @@ def main():
             eng = fd.SlabEngine(plan, h, dist)
 
             def step():
-                return eng.filter_3d(vol, kernels, params)
+                _live["py_out"] = eng.filter_3d(vol, kernels, params)      # a view of an engine-owned buffer
+                return None
             backend = dist.get_backend()
             parallelism = f"{world} Z-slabs, one exchange per pass (halos + repartition), torch.distributed point-to-point ({backend}); slab engine above the C ABI"
         if rehearsal:
-            parallelism = f"REHEARSAL: {world} ranks sharing {ngpu} GPU(s), exchanges staged through host memory (not a measurement)"
+            parallelism = (f"REHEARSAL: {world} ranks on {len(set(devices))} distinct GPU(s) ({', '.join(sorted(set(devices)))}), exchanges "
+                           "staged through host memory (not a measurement)")
 
     def barrier():
         if tr is not None:
@@ -508,7 +573,10 @@ def main():
             "value": round(value, 3), "unit": "Mvoxels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "n_ranks_seen": world,
+            "n_ranks_seen": n_seen,
+            "n_ranks_seen_source": ("ncclCommCount of the live communicator" if tr is not None and tr.kind == "rccl" else
+                                    "distinct ranks the shared-memory transport heard from" if tr is not None else
+                                    "torch.distributed.get_world_size()" if dist is not None else "single process"),
             "backend": backend,
             "config": {"workload": f"{X}x{Y}x{Z} float32, sigma={a.sigmas or format(a.sigma, 'g')} (K={','.join(str(k.size) for k in ks3)}), levels={a.levels}, winsize={a.winsize}, "
                                    f"OF along {a.axes.upper()}, mean-padded borders ({tag})",
@@ -519,6 +587,9 @@ def main():
         }
         if tr is not None:
             res["transport"] = tr.describe()
+        if devices is not None:
+            res["devices"] = devices         # hipDeviceGetPCIBusId of every rank, all-gathered: N distinct strings = N distinct GPUs
+            res["distinct_devices"] = len(set(devices))
         if fallback:
             res["transport_fallback"] = fallback
         # whole path against the SURVEY 8(d) stage list (4832 B/voxel/axis at sigma=2): what an UNFUSED implementation
@@ -542,23 +613,46 @@ def main():
             if a.levels == 0:
                 h.enable_timers(True)
                 res["sweep"] = sweep_line(h, vol, shape, kernel, params, mean)
-        elif tr is not None:
-            chk = check_sharded(h, tr, dev, rank, world, shape, kernels, params, a.amplitude, out_slab, a.levels)
+        else:
+            if tr is not None:
+                move = (lambda t: tr.exchange([(t.data_ptr(), t.numel() * 4, 0, True)], 0),
+                        lambda lst: tr.exchange([(t.data_ptr(), t.numel() * 4, r, False) for r, t in lst], 0), barrier)
+            else:
+                host = dist.get_backend() == "gloo"
+
+                def send_to_0(t):
+                    dist.send(t.cpu() if host else t, 0)
+
+                def recv_from(lst):
+                    for r, t in lst:
+                        if host:
+                            buf = torch.empty(t.shape, dtype=t.dtype)
+                            dist.recv(buf, r)
+                            t.copy_(buf)
+                        else:
+                            dist.recv(t, r)
+                move = (send_to_0, recv_from, barrier)
+                if out_slab is None:
+                    out_slab = _live["py_out"].contiguous()
+            chk = check_sharded(h, move, dev, rank, world, shape, kernels, params, a.amplitude, out_slab, a.levels)
             if rank == 0:
                 res["checked"] = chk
     h.enable_timers(False)
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(vol, shape, kernel, mean, a.cpu_targets, a.levels, a.winsize)
+        elif world > 1:
+            res["cpu_baseline"] = None
+            res["cpu_baseline_see"] = "the N = 1 line: the CPU sample is timed on rank 0 at N = 1 only"
         print(json.dumps(res), flush=True)
     barrier()
     if dist is not None:
         dist.destroy_process_group()
     if tr is not None:
         tr.close()
-        if rank == 0 and "FDN_RDV" not in os.environ:      # a rendezvous directory derived under torch.distributed.run: ours to remove
-            import shutil
-            shutil.rmtree(rdv, ignore_errors=True)
+        _live.pop("tr", None)
+    if rank == 0 and rdv is not None:
+        launch.remove_derived_rendezvous(rdv)       # a directory derived under torch.distributed.run is ours to remove
 
 
 if __name__ == "__main__":

@@ -43,7 +43,7 @@ DEPTHS = {np.dtype(np.float32): DEPTH_F32, np.dtype(np.float64): DEPTH_F64, np.d
 
 # every symbol include/flowdn.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "fdn_create", "fdn_device_count", "fdn_destroy", "fdn_last_error", "fdn_set_stream", "fdn_reset_stream", "fdn_synchronize",
+    "fdn_create", "fdn_device_count", "fdn_device_pci_id", "fdn_destroy", "fdn_last_error", "fdn_set_stream", "fdn_reset_stream", "fdn_synchronize",
     "fdn_set_workspace_limit", "fdn_workspace_bytes", "fdn_mem_info", "fdn_set_option", "fdn_malloc", "fdn_free", "fdn_memcpy_h2d", "fdn_memcpy_d2h",
     "fdn_memcpy2d_h2d", "fdn_memcpy2d_d2h", "fdn_host_register", "fdn_host_unregister",
     "fdn_memset_f32", "fdn_gaussian_kernel", "fdn_farneback", "fdn_farneback_strided", "fdn_farneback_dev",
@@ -74,7 +74,8 @@ RCCL_LIB_PATH = os.path.join(_HERE, "libflowdn_rccl.so")
 TRANSPORT_RCCL, TRANSPORT_SHM, TRANSPORT_NULL = 0, 1, 2
 # every symbol include/flowdn_rccl.h declares
 RCCL_EXPORTS = ["fdn_transport_create", "fdn_transport_destroy", "fdn_transport_last_error", "fdn_transport_describe",
-                "fdn_transport_comm", "fdn_transport_exchange", "fdn_transport_allgather_host", "fdn_transport_barrier"]
+                "fdn_transport_comm", "fdn_transport_exchange", "fdn_transport_allgather_host", "fdn_transport_barrier",
+                "fdn_transport_count", "fdn_transport_device_id", "fdn_transport_abort"]
 _torch_runtime = None      # directory of the torch-bundled ROCm libraries when libflowdn.so was bound to them
 
 
@@ -153,6 +154,9 @@ def load_rccl():
     lib.fdn_transport_describe.argtypes = [ctypes.c_void_p]
     lib.fdn_transport_comm.restype = ctypes.c_void_p
     lib.fdn_transport_comm.argtypes = [ctypes.c_void_p]
+    lib.fdn_transport_count.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    lib.fdn_transport_device_id.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+    lib.fdn_transport_abort.argtypes = [ctypes.c_void_p]
     _rccl = lib
     return lib
 
@@ -178,6 +182,28 @@ class Transport:
 
     def describe(self):
         return self._lib.fdn_transport_describe(self._t).decode()
+
+    def count(self):
+        """Ranks as the communicator itself reports them (RCCL: ncclCommCount)."""
+        n = ctypes.c_int()
+        self._check(self._lib.fdn_transport_count(self._t, ctypes.byref(n)))
+        return n.value
+
+    def device_id(self):
+        """PCI bus id of this rank's device ("host" without one)."""
+        buf = ctypes.create_string_buffer(64)
+        self._check(self._lib.fdn_transport_device_id(self._t, buf, ctypes.c_int(64)))
+        return buf.value.decode()
+
+    def devices(self):
+        """Every rank's device_id(), in rank order (collective)."""
+        raw = self.allgather_host(self.device_id().encode().ljust(64, b"\0"))
+        return [raw[i * 64:(i + 1) * 64].rstrip(b"\0").decode() for i in range(self.world)]
+
+    def abort(self):
+        """Tell the other ranks that this one cannot go on (they stop waiting); only close() may follow."""
+        if self._t:
+            self._lib.fdn_transport_abort(self._t)
 
     def comm_ptr(self):
         """const fdn_comm* for fdn_filter_3d_sharded."""
@@ -255,6 +281,13 @@ def device_count():
     n = ctypes.c_int()
     check(load().fdn_device_count(ctypes.byref(n)))
     return n.value
+
+
+def device_pci_id(device):
+    """PCI bus id of a visible HIP device (fdn_device_pci_id)."""
+    buf = ctypes.create_string_buffer(64)
+    check(load().fdn_device_pci_id(ctypes.c_int(int(device)), buf, ctypes.c_int(64)))
+    return buf.value.decode()
 
 
 def combine_slice_stats(first, count, second=None):

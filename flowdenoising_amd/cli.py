@@ -148,6 +148,23 @@ def _run_sharded(args, shape, kernels, l, w, stats, job, wall):
     rank, world, local, rdv = job
     tr, device = launch.make_transport(rank, world, local, rdv)
     logging.info(f"rank {rank}: {tr.describe()}")
+    try:
+        return _run_sharded_rank(args, shape, kernels, l, w, stats, wall, tr, device, rank, world)
+    except BaseException as e:      # noqa: BLE001 -- a reader, a writer or the filter failed on THIS rank: the others are told
+        launch.report_failure(rdv, rank, f"{type(e).__name__}: {e}")      # before this rank leaves (they would wait in an
+        tr.abort()                                                       # exchange or at a barrier until their timeout)
+        raise
+    finally:
+        tr.close()
+        if rank == 0:
+            launch.remove_derived_rendezvous(rdv)
+
+
+def _run_sharded_rank(args, shape, kernels, l, w, stats, wall, tr, device, rank, world):
+    from . import _lib
+    from . import io as fio
+    from .distributed import split
+    from .operators import _download_into, _params, integer_semantics
     h = _lib.Handle(device)
     Z, Y, X = shape
     parts = split(Z, world)
@@ -217,7 +234,6 @@ def _run_sharded(args, shape, kernels, l, w, stats, job, wall):
     finally:
         h.free(d_out)
         h.free(d_in)
-        tr.close()
         h.close()
     return None
 
@@ -250,6 +266,13 @@ def main(argv=None):
         parser.error("--gpus shards the volume over GPUs 0..N-1 and keeps every slab resident: "
                      "it cannot be combined with --chunk_slices or --device")
     if args.gpus > 1 and not sharded:
+        from . import io as fio
+        try:
+            hshape, _ = fio.volume_info(args.input)
+        except Exception as e:
+            parser.error(f"cannot read {args.input}: {e}")
+        if args.gpus > min(hshape):
+            parser.error(f"--gpus {args.gpus}: every axis of the volume must have at least one slice per rank, its shape is {tuple(hshape)}")
         # the parent: N rank processes of this same command, started with plain subprocess.Popen before anything here has
         # touched a GPU (never an exec); they meet through the native transport (include/flowdn_rccl.h) -- no PyTorch
         script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flowdenoising.py")

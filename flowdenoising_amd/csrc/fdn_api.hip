@@ -1844,6 +1844,15 @@ FDN_API int fdn_device_count(int* count_out)
     return 0;
 }
 
+FDN_API int fdn_device_pci_id(int device, char* buf, int cap)
+{
+    if (!buf || cap < 1) return fail("buf is NULL");
+    buf[0] = 0;
+    hipError_t e = hipDeviceGetPCIBusId(buf, cap, device);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail("hipDeviceGetPCIBusId(%d): %s", device, hipGetErrorString(e)); }
+    return 0;
+}
+
 FDN_API int fdn_convert_dev(fdn_handle h, const void* d_src, int depth, float* d_dst, size_t count)
 {
     FDN_ENTER(h);

@@ -10,6 +10,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <future>
+#include <memory>
+#include <thread>
 #include <cerrno>
 #include <cstdarg>
 #include <cstdio>
@@ -98,8 +102,13 @@ struct fdn_transport {
     // RCCL
     ncclComm_t nccl = nullptr;
     hipStream_t side = nullptr;                // stream of the host all-gather
+    hipEvent_t order = nullptr;                // ... ordered behind the stream the last exchange was enqueued on
+    hipStream_t last = nullptr;                // that stream
+    bool have_last = false;
     char* stage = nullptr;                     // device staging of the host all-gather
     size_t stage_cap = 0;
+    int count = 0;                             // ranks the communicator itself reports (ncclCommCount; SHM: ranks met at the first barrier)
+    std::string device_id;                     // PCI bus id of this rank's device ("host": no device)
     // SHM
     std::string dir;
     Ctl* ctl = nullptr;
@@ -134,6 +143,27 @@ int write_file_atomically(const std::string& path, const void* data, size_t byte
 }
 
 // ---- RCCL ---------------------------------------------------------------------------------------------------------
+// wait for what is enqueued on `st`, at most `limit` seconds: a peer that never posts its half of an exchange must end in
+// an error here, not in a process that hangs until somebody's outer timeout
+int wait_stream(hipStream_t st, double limit, const char* what)
+{
+    const double t0 = now_s();
+    for (int spins = 0;; spins++) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return fail("%s: %s", what, hipGetErrorString(e));
+        if (now_s() - t0 > limit) return fail("%s did not complete within %.0f s (a peer is missing or the links are down)", what, limit);
+        nap(spins);
+    }
+}
+
+double sanity_timeout()
+{
+    const char* e = getenv("FDN_RCCL_SANITY_TIMEOUT");
+    const double v = e ? atof(e) : 0.;
+    return v > 0. ? v : 120.;
+}
+
 int rccl_init(fdn_transport* t, const char* rendezvous)
 {
     static std::atomic<int> seq{0};            // several communicators of one job: all ranks create them in the same order
@@ -151,8 +181,56 @@ int rccl_init(fdn_transport* t, const char* rendezvous)
         if (!f || fread(&id, 1, sizeof id, f) != sizeof id) { if (f) fclose(f); return fail("cannot read %s", path.c_str()); }
         fclose(f);
     }
-    T_NCCL(ncclCommInitRank(&t->nccl, t->world, id, t->rank));
+    if (t->world == 1) T_NCCL(ncclCommInitRank(&t->nccl, 1, id, 0));
+    else {
+        // ncclCommInitRank blocks until every rank has joined and has no timeout of its own: it runs in a helper thread that
+        // is given rdv_timeout() seconds (a rank that died, IPC handles the driver refuses ...).  On a timeout the thread is
+        // left behind -- the caller is expected to end the process (flowdenoising_amd/launch.py does, with os._exit).
+        struct Shared { ncclComm_t comm = nullptr; ncclResult_t res = ncclSuccess; hipError_t dev = hipSuccess; };
+        auto sh = std::make_shared<Shared>();
+        std::promise<void> done;
+        std::future<void> fut = done.get_future();
+        const int world = t->world, rank = t->rank, device = t->device;
+        std::thread th([sh, id, world, rank, device](std::promise<void> p) {
+            sh->dev = hipSetDevice(device);
+            if (sh->dev == hipSuccess) sh->res = ncclCommInitRank(&sh->comm, world, id, rank);
+            p.set_value();
+        }, std::move(done));
+        const double limit = rdv_timeout();
+        if (fut.wait_for(std::chrono::duration<double>(limit)) != std::future_status::ready) {
+            th.detach();
+            return fail("ncclCommInitRank (rank %d of %d, device %d) did not return within %.0f s: a rank is missing, or RCCL cannot "
+                        "share memory between the ranks' processes (HSA_ENABLE_IPC_MODE_LEGACY=0 must be set on this host driver)",
+                        rank, world, device, limit);
+        }
+        th.join();
+        if (sh->dev != hipSuccess) return fail("hipSetDevice(%d): %s", device, hipGetErrorString(sh->dev));
+        if (sh->res != ncclSuccess) return fail("ncclCommInitRank: %s", ncclGetErrorString(sh->res));
+        t->nccl = sh->comm;
+    }
     T_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+    T_HIP(hipEventCreateWithFlags(&t->order, hipEventDisableTiming));
+    T_NCCL(ncclCommCount(t->nccl, &t->count));
+    if (t->count != t->world) return fail("the communicator reports %d ranks, %d expected", t->count, t->world);
+    if (t->world > 1) {
+        // a first, small exchange under a deadline: every rank sends its rank number round a ring -- the calls of a real
+        // exchange (grouped ncclSend / ncclRecv); links or IPC that do not work show here, in seconds, with a message
+        int* buf = nullptr;
+        T_HIP(hipMalloc((void**)&buf, 512));
+        const int mine = t->rank, next = (t->rank + 1) % t->world, prev = (t->rank + t->world - 1) % t->world;
+        int got = -1;
+        T_HIP(hipMemcpy(buf, &mine, sizeof mine, hipMemcpyHostToDevice));
+        T_NCCL(ncclGroupStart());
+        const ncclResult_t r1 = ncclSend(buf, 64, ncclInt8, next, t->nccl, t->side);
+        const ncclResult_t r2 = ncclRecv((char*)buf + 256, 64, ncclInt8, prev, t->nccl, t->side);
+        const ncclResult_t r3 = ncclGroupEnd();
+        if (r1 != ncclSuccess || r2 != ncclSuccess || r3 != ncclSuccess)
+            return fail("first exchange: %s", ncclGetErrorString(r1 != ncclSuccess ? r1 : r2 != ncclSuccess ? r2 : r3));
+        if (wait_stream(t->side, sanity_timeout(), "the first ncclSend / ncclRecv exchange between the ranks")) return -1;
+        T_HIP(hipMemcpy(&got, (char*)buf + 256, sizeof got, hipMemcpyDeviceToHost));
+        (void)hipFree(buf);
+        if (got != prev) return fail("first exchange: rank %d received %d from rank %d", t->rank, got, prev);
+    }
     int ver = 0;
     (void)ncclGetVersion(&ver);
     char buf[160];
@@ -176,20 +254,29 @@ int rccl_exchange(fdn_transport* t, int n, const fdn_msg* msgs, hipStream_t st)
     const ncclResult_t end = ncclGroupEnd();
     if (bad != ncclSuccess) return fail("ncclSend/ncclRecv: %s", ncclGetErrorString(bad));
     if (end != ncclSuccess) return fail("ncclGroupEnd: %s", ncclGetErrorString(end));
+    t->last = st; t->have_last = true;
     return 0;
 }
 
+// One communicator, two streams (the caller's for the exchanges, `side` for this host-level gather): RCCL wants the operations
+// of a communicator issued in one order on every rank, so the gather is ordered behind whatever the last exchange left in
+// flight on the caller's stream (an event there, waited for on `side`) -- and it has completed before this returns.
 int rccl_allgather_host(fdn_transport* t, const void* send, void* recv, size_t bytes)
 {
     if (!bytes) return 0;
-    const size_t need = bytes * (size_t)(t->world + 1);
+    const size_t slot = (bytes + 255) & ~(size_t)255;           // `all` starts on a 256-byte boundary whatever `bytes` is
+    const size_t need = slot + bytes * (size_t)t->world;
     if (t->stage_cap < need) {
         if (t->stage) { T_HIP(hipStreamSynchronize(t->side)); T_HIP(hipFree(t->stage)); t->stage = nullptr; t->stage_cap = 0; }
         T_HIP(hipMalloc((void**)&t->stage, need));
         t->stage_cap = need;
     }
     char* mine = t->stage;
-    char* all = t->stage + bytes;
+    char* all = t->stage + slot;
+    if (t->have_last) {
+        T_HIP(hipEventRecord(t->order, t->last));
+        T_HIP(hipStreamWaitEvent(t->side, t->order, 0));
+    }
     T_HIP(hipMemcpyAsync(mine, send, bytes, hipMemcpyHostToDevice, t->side));
     T_NCCL(ncclAllGather(mine, all, bytes, ncclInt8, t->nccl, t->side));
     T_HIP(hipMemcpyAsync(recv, all, bytes * (size_t)t->world, hipMemcpyDeviceToHost, t->side));
@@ -268,6 +355,7 @@ int shm_init(fdn_transport* t, const char* rendezvous)
     t->in.resize(t->world);
     if (shm_map(t->out, out_path(t, t->rank), kHeaderBytes, true)) return -1;
     if (shm_barrier(t)) return -1;             // every outbox exists
+    t->count = t->world;                       // (fdn_transport_create counts the distinct ranks it actually hears from)
     char buf[160];
     snprintf(buf, sizeof buf, "shm (host-staged, ranks share devices), rank %d of %d, device %d", t->rank, t->world, t->device);
     t->what = buf;
@@ -378,6 +466,20 @@ FDN_API int fdn_transport_create(int kind, int rank, int world, int device, cons
         else if (kind == FDN_TRANSPORT_SHM) rc = shm_init(t, rendezvous);
         else rc = fail("unknown transport kind %d", kind);
     }
+    if (!rc && kind == FDN_TRANSPORT_NULL) t->count = world;
+    if (!rc && kind == FDN_TRANSPORT_SHM) {    // who is there: every rank's number gathered once, distinct ones counted
+        std::vector<int> all(world, -1);
+        const int mine = rank;
+        rc = shm_allgather_host(t, &mine, all.data(), sizeof mine);
+        std::sort(all.begin(), all.end());
+        t->count = (int)(std::unique(all.begin(), all.end()) - all.begin());
+        if (!rc && t->count != world) rc = fail("shm transport: %d distinct ranks answered, %d expected", t->count, world);
+    }
+    if (!rc) {
+        char id[64] = "host";
+        if (device >= 0 && hipDeviceGetPCIBusId(id, (int)sizeof id, device) != hipSuccess) { (void)hipGetLastError(); snprintf(id, sizeof id, "device %d", device); }
+        t->device_id = id;
+    }
     if (rc) { const std::string keep = g_err; fdn_transport_destroy(t); g_err = keep; return -1; }
     *out = t;
     return 0;
@@ -391,6 +493,7 @@ FDN_API int fdn_transport_destroy(fdn_transport_t t)
         if (t->side) { (void)hipStreamSynchronize(t->side); }
         if (t->nccl) (void)ncclCommDestroy(t->nccl);
         if (t->stage) (void)hipFree(t->stage);
+        if (t->order) (void)hipEventDestroy(t->order);
         if (t->side) (void)hipStreamDestroy(t->side);
     }
     if (t->kind == FDN_TRANSPORT_SHM) {
@@ -403,6 +506,29 @@ FDN_API int fdn_transport_destroy(fdn_transport_t t)
 }
 
 FDN_API const char* fdn_transport_describe(fdn_transport_t t) { return t ? t->what.c_str() : ""; }
+
+FDN_API int fdn_transport_count(fdn_transport_t t, int* out)
+{
+    if (!t || !out) return fail("transport / out is NULL");
+    *out = t->count;
+    if (t->kind == FDN_TRANSPORT_RCCL) T_NCCL(ncclCommCount(t->nccl, out));      // asked again: the live communicator's own answer
+    return 0;
+}
+
+FDN_API int fdn_transport_device_id(fdn_transport_t t, char* buf, int cap)
+{
+    if (!t || !buf || cap < 1) return fail("transport / buf is NULL");
+    snprintf(buf, (size_t)cap, "%s", t->device_id.c_str());
+    return 0;
+}
+
+FDN_API int fdn_transport_abort(fdn_transport_t t)
+{
+    if (!t) return 0;
+    if (t->kind == FDN_TRANSPORT_SHM && t->ctl) t->ctl->failed.store(1);
+    if (t->kind == FDN_TRANSPORT_RCCL && t->nccl) { (void)ncclCommAbort(t->nccl); t->nccl = nullptr; }
+    return 0;
+}
 
 FDN_API const fdn_comm* fdn_transport_comm(fdn_transport_t t)
 {

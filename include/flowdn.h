@@ -81,6 +81,9 @@ int fdn_create(int device, fdn_handle* out);
 /* HIP devices visible to this process (0 when there is none or the runtime cannot start): what a rank of a multi-GPU run
  * compares with the number of ranks to choose between one GPU each (RCCL) and sharing (include/flowdn_rccl.h). */
 int fdn_device_count(int* count_out);
+/* PCI bus id of device `device` ("0000:05:00.0"): what tells ranks on one GPU from ranks on GPUs of their own when a
+ * launcher has narrowed each rank's view to one device (HIP_VISIBLE_DEVICES). */
+int fdn_device_pci_id(int device, char* buf, int cap);
 int fdn_destroy(fdn_handle h);
 const char* fdn_last_error(void);
 /* Enqueue on an external HIP stream instead (e.g. torch.cuda.current_stream().cuda_stream, so that

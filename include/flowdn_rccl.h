@@ -11,8 +11,11 @@
  *
  *   FDN_TRANSPORT_RCCL   one GPU per rank.  exchange = ncclGroupStart(); ncclSend / ncclRecv per message on the
  *                        caller's stream; ncclGroupEnd() -- point-to-point over xGMI, every pair at once, nothing
- *                        synchronises the host.  allgather_host = ncclAllGather on a device staging buffer.  The
- *                        ncclUniqueId travels from rank 0 to the others through a file in the rendezvous directory.
+ *                        synchronises the host.  allgather_host = ncclAllGather on a device staging buffer, on a stream of
+ *                        its own that is ordered (event) behind the stream of the last exchange.  The ncclUniqueId
+ *                        travels from rank 0 to the others through a file in the rendezvous directory; ncclCommInitRank
+ *                        is given FDN_RDV_TIMEOUT seconds, and a first ring exchange FDN_RCCL_SANITY_TIMEOUT (120):
+ *                        IPC or links that do not work end in an error message, not in a hang.
  *   FDN_TRANSPORT_SHM    ranks that share a GPU (a rehearsal of N ranks on a one-GPU box; RCCL refuses two ranks on
  *                        one device): messages are staged through POSIX shared memory files in the rendezvous
  *                        directory.  Same schedule, same kernels; not a measurement of anything.
@@ -49,6 +52,18 @@ int fdn_transport_destroy(fdn_transport_t t);
 const char* fdn_transport_last_error(void);
 /* "rccl 2.x.y, 8 ranks, device 3" / "shm, 2 ranks ..." */
 const char* fdn_transport_describe(fdn_transport_t t);
+
+/* Who is there, as the communicator itself says it -- not as the launcher's environment claims: RCCL: ncclCommCount of
+ * the live communicator; SHM: the distinct ranks that answered the first all-gather; NULL: `world`.  bench.py prints it
+ * as `n_ranks_seen`. */
+int fdn_transport_count(fdn_transport_t t, int* out);
+/* The PCI bus id of this rank's device (hipDeviceGetPCIBusId, e.g. "0000:05:00.0"; "host" for device -1): all-gathered,
+ * N distinct strings show N distinct GPUs -- a run whose ranks share devices is a rehearsal and says so. */
+int fdn_transport_device_id(fdn_transport_t t, char* buf, int cap);
+/* A rank that cannot go on (a reader or writer failed, an exception above the ABI) tells the others before it leaves, so
+ * that they stop waiting: SHM sets the job's failed flag, RCCL aborts the communicator (ncclCommAbort).  The transport
+ * can only be destroyed afterwards. */
+int fdn_transport_abort(fdn_transport_t t);
 
 /* The communicator to hand to fdn_filter_3d_sharded (valid until fdn_transport_destroy). */
 const fdn_comm* fdn_transport_comm(fdn_transport_t t);

@@ -792,3 +792,105 @@ def _write_mrc_any(path, vol):
     with open(path, "wb") as f:
         f.write(h)
         f.write(np.ascontiguousarray(vol).tobytes())
+
+
+# ---- the C engine at world 7 and 8: rank THREADS in this process (the boxes allow six GPU processes) -----------------------
+@pytest.mark.parametrize("world,shape,sig,border,l,w,dtype", [
+    (8, (16, 66, 140), "1.0,0.5,1.0", 0, 0, 5, np.float32),      # two slices per rank, mean-padded
+    (8, (19, 70, 64), "1.5,1.5,-", 1, 0, 5, np.float32),         # wrap-around; K//2 = 6 exceeds every slab (2-3 slices): halos from three ranks away
+    (7, (16, 66, 140), "1.0,1.0,0.5", 0, 1, 7, np.float32),      # a pyramid level on the Z pass's images (66 x 140), uneven slabs
+    (8, (17, 40, 72), "1.0,0.5,1.0", 0, 0, 5, np.int16),         # seq on an integer volume: the float64 padded volume through every exchange
+    (7, (15, 64, 66), "0.5,1.0,1.0", 1, 0, 15, np.int16),        # par on an integer volume, the one-iteration kernel
+])
+def test_native_engine_world_7_and_8_as_rank_threads(fdn, world, shape, sig, border, l, w, dtype):
+    """fdn_filter_3d_sharded -- plan, packing, one exchange per pass, the exact mean, the passes -- at world = 7 and 8 on one
+    GPU: every rank a thread with its own handle, stream and shared-memory transport (tests/_thread_ranks.py); the
+    concatenated slabs equal the single-GPU OF_filter bit for bit.  (src/flowdenoising.py:181-206 is the decomposition this
+    replaces; the driver's 8-GPU box runs the same engine over RCCL.)"""
+    import _thread_ranks
+    from flowdenoising_amd import _lib, operators
+    vol = _vol(shape, seed=41)
+    if dtype is not np.float32:
+        vol = np.round((vol - vol.min()) * (3000.0 / (vol.max() - vol.min())) - 700).astype(dtype)
+    ks = [None if s == "-" else fdn.get_gaussian_kernel(float(s)) for s in sig.split(",")]
+    want = fdn.OF_filter(vol, ks, l, w, border_mode=border)
+    p = operators.integer_semantics(vol, operators._params(l, w, True, border, True))
+    got, info = _thread_ranks.run(vol.astype(np.float32), ks, p, world)
+    print(info)
+    assert info["count"] == world and len(info["devices"]) == world and len(set(info["devices"])) == 1      # one GPU: a rehearsal, and it says so
+    if border == _lib.BORDER_WRAP and dtype is not np.float32:
+        want = want.astype(np.float32)          # par keeps the integer dtype on the host side; the engine's slabs are float32 holding integers
+    assert got.dtype == np.float32 and np.array_equal(got, want.astype(np.float32))
+
+
+def _bench_line(stdout):
+    import json
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_proves_its_ranks_and_devices(fdn):
+    """The N > 1 line says who was there as the communicator reports it (`n_ranks_seen` = ncclCommCount over RCCL, the
+    distinct ranks heard from over shared memory) and which GPU every rank sat on (`devices`: all-gathered PCI bus ids):
+    N distinct strings or the line calls itself a REHEARSAL.  cpu_baseline is null with a pointer to the N = 1 line; the
+    roofline block stays."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--shape", "24,96,160", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _bench_line(r.stdout)
+    assert d["n_ranks_seen"] == 3 and len(d["devices"]) == 3 and d["distinct_devices"] == len(set(d["devices"]))
+    assert ("REHEARSAL" in d["config"]["parallelism"]) == (d["distinct_devices"] < 3)
+    assert d["cpu_baseline"] is None and "N = 1" in d["cpu_baseline_see"] and d["roofline"]["frac"] > 0
+    assert "transport_fallback" not in d and d["checked"]["ok"]
+
+
+@pytest.mark.parametrize("how", ["bare", "torchrun"])
+def test_bench_falls_back_to_fresh_ranks_when_the_native_job_fails(fdn, how):
+    """A native start-up failure must not leave an `rc != 0` record without a number.  From a bare shell the parent -- which
+    never touched a GPU -- starts N fresh children once more on the torch.distributed engine; under torch.distributed.run
+    every rank runs its native rank in one child of its own, and when that job fails anywhere all ranks (still fresh) carry
+    on with the torch.distributed engine in themselves.  Either way the line says `transport_fallback` and why, and still
+    checks its output.  (FDN_TEST_FAIL_NATIVE=1: native rank 1 raises after the transport is up -- rank 0 is then waiting
+    in a collective and has to be told.)"""
+    import socket
+    pytest.importorskip("torch")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "FDN_RANK", "FDN_WORLD", "FDN_RDV")}
+    env["FDN_TEST_FAIL_NATIVE"] = "1"
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shape", "24,96,160", "--steps", "1", "--warmup", "0"]
+    if how == "torchrun":
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
+    else:
+        cmd = [sys.executable] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _bench_line(r.stdout)
+    assert "injected failure" in d["transport_fallback"] and d["backend"] in ("nccl", "gloo")
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["value"] > 0 and len(d["devices"]) == 2
+    assert d["checked"]["ok"] and d["checked"]["sharded_output_equals_single_gpu_rerun"]
+    # and without the fallback the failure is the exit code, promptly
+    env["FDN_BENCH_NO_FALLBACK"] = "1"
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "injected failure" in r.stderr
+
+
+def test_cli_gpus_refuses_more_ranks_than_slices_and_a_failing_rank_stops_the_job(fdn, tmp_path):
+    """`--gpus N` with an axis shorter than N is refused by the parent, before any rank starts; a rank that fails (rank 0
+    cannot create the output file) tells the others, which leave their barrier at once instead of waiting for the timeout."""
+    import time
+    from flowdenoising_amd import io as fio
+    v = _vol((3, 40, 72), seed=12)
+    src = str(tmp_path / "in.mrc")
+    fio.write_volume(src, v)
+    env = {k: val for k, val in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FDN_RANK", "FDN_WORLD", "FDN_RDV")}
+    cli = [sys.executable, os.path.join(ROOT, "flowdenoising.py"), "-i", src, "-s", "1.0", "0.5", "1.0"]
+    r = subprocess.run(cli + ["-o", str(tmp_path / "o.mrc"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "--gpus 4" in r.stderr
+    t0 = time.perf_counter()
+    r = subprocess.run(cli + ["-o", str(tmp_path / "no_such_dir" / "o.mrc"), "--gpus", "2"], env=dict(env, FDN_RDV_TIMEOUT="120"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and time.perf_counter() - t0 < 60, r.stderr[-2000:]

@@ -70,3 +70,66 @@ def test_shm_transport_gives_up_when_a_rank_never_arrives(fdn, tmp_path):
             "try:\n    _lib.Transport('shm', 0, 2, -1, %r)\nexcept _lib.FlowdnError as e:\n    print('gave up:', e)\n") % (ROOT, str(tmp_path))
     r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=120)
     assert "gave up" in r.stdout and "barrier" in r.stdout, r.stdout + r.stderr
+
+
+def test_shm_transport_with_eight_rank_threads_in_one_process(fdn, tmp_path):
+    """The ranks of the shared-memory transport as THREADS of one process (how the GPU tests rehearse world = 7 and 8 on
+    a box that allows six GPU processes): the control block's barrier, the outboxes and the error strings hold up; the
+    communicator's own rank count and the all-gathered device ids come back; a rank that aborts stops the others."""
+    import threading
+    world, errors, seen = 8, [], {}
+
+    def rank_main(r):
+        try:
+            t = fdn._lib.Transport("shm", r, world, -1, str(tmp_path))
+            for rnd in range(3):
+                sends = {j: np.full(500 + 13 * r + 7 * j, 100.0 * r + j + rnd, dtype=np.float32) for j in range(world) if j != r}
+                recvs = {i: np.zeros(500 + 13 * i + 7 * r, dtype=np.float32) for i in range(world) if i != r}
+                t.exchange([(a.ctypes.data, a.nbytes, i, False) for i, a in recvs.items()] + [(a.ctypes.data, a.nbytes, j, True) for j, a in sends.items()], 0)
+                for i, a in recvs.items():
+                    assert np.all(a == np.float32(100.0 * i + r + rnd)), (rnd, r, i)
+            assert t.count() == world
+            assert t.devices() == ["host"] * world
+            assert t.allgather_host(bytes([r]) * 3) == b"".join(bytes([q]) * 3 for q in range(world))      # 3 bytes: the staging stays aligned
+            t.barrier()
+            seen[r] = t.describe()
+            t.close()
+        except BaseException as e:      # noqa: BLE001
+            errors.append((r, e))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    assert not errors, errors
+    assert len(seen) == world and "rank 0 of 8" in seen[0]
+
+
+def test_an_aborting_rank_stops_the_waiting_ones(fdn, tmp_path):
+    import threading
+    import time
+    out = {}
+
+    def waiter():
+        t = fdn._lib.Transport("shm", 0, 2, -1, str(tmp_path))
+        try:
+            t.barrier()
+            out["waiter"] = "passed"
+        except fdn._lib.FlowdnError as e:
+            out["waiter"] = str(e)
+        t.close()
+
+    def quitter():
+        t = fdn._lib.Transport("shm", 1, 2, -1, str(tmp_path))
+        time.sleep(0.5)
+        t.abort()
+        t.close()
+
+    ths = [threading.Thread(target=waiter), threading.Thread(target=quitter)]
+    t0 = time.perf_counter()
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join(timeout=60)
+    assert "another rank failed" in out["waiter"] and time.perf_counter() - t0 < 30
