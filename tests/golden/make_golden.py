@@ -172,6 +172,43 @@ def sweeps():
     save("ref_sweep_par_u8_l0_w5.npz", vol=vpu, sigmas=np.array(sig), l=np.array(0), w=np.array(5), chained=np.array(1), out_zy=zy, out_zyx=zyx)
 
 
+def sweeps_with_levels():
+    """Round 5: real pyramid levels OFF the Z axis under the reference's control flow.  cv2 keeps level
+    k only while both image sides times 0.5^k stay >= 32, so every image of a pass needs sides >= 64: a 64 x 64 x 72 volume
+    gives the Y pass (Z x X = 64 x 72) and the X pass (Z x Y = 64 x 64) one coarser level, like the Z pass.
+      ref_sweep_seq_lv_f32_l1_w7.npz   seq.OF_filter, float32, -l 1 -w 7
+      ref_sweep_seq_lv_i16_l1_w7.npz   seq.OF_filter on an int16 volume (float64 padded volume), -l 1 -w 7
+      ref_sweep_par_lv_f32_l3_w5.npz   par's FlowDenoising(...).filter(kernels) at par's own default l = 3 (par:48), w = 5"""
+    cv2 = OracleCv2()
+    seq = load_reference(REF, "fd_seq_reference_cv", cv2)
+    par = load_reference(REF_PAR, "fd_par_reference_cv", cv2)
+    sig = [1.0, 0.5, 1.0]
+    ks = [seq.get_gaussian_kernel(s) for s in sig]
+
+    def save(name, **kw):
+        np.savez_compressed(os.path.join(HERE, name), cv2_calls=np.array(CV2_NOTE), **kw)
+        print(name, {k: (v.shape, str(v.dtype)) for k, v in kw.items() if hasattr(v, "shape") and v.ndim})
+
+    shape = (64, 64, 72)
+    vol = volume(shape, 111)
+    out = seq.OF_filter(vol.copy(), ks, 1, 7)
+    assert out.dtype == np.float32
+    save("ref_sweep_seq_lv_f32_l1_w7.npz", vol=vol, sigmas=np.array(sig), l=np.array(1), w=np.array(7), out=out)
+    vi = volume(shape, 112, np.int16)
+    out = seq.OF_filter(vi.copy(), ks, 1, 7)
+    assert out.dtype == np.float32
+    save("ref_sweep_seq_lv_i16_l1_w7.npz", vol=vi, sigmas=np.array(sig), l=np.array(1), w=np.array(7), out=out)
+
+    par.args = types.SimpleNamespace(input="fixture")
+    vp = volume(shape, 113)
+    v = vp.copy()
+    par.l, par.w, par.get_flow, par.vol = 3, 5, par.get_flow_with_prev_flow, v
+    fd = par.FlowDenoising(3, v, 3, 5, par.get_flow_with_prev_flow, par.warp_slice)
+    assert fd.filter(ks) is None
+    save("ref_sweep_par_lv_f32_l3_w5.npz", vol=vp, sigmas=np.array(sig), l=np.array(3), w=np.array(5), chained=np.array(1),
+         out_zy=fd.vol.copy(), out_zyx=fd.filtered_vol.copy())
+
+
 def main():
     seq = load_seq()
     sigmas = [0.1, 0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 4.0]
@@ -191,6 +228,10 @@ def main():
 
 
 if __name__ == "__main__":
-    if "--sweeps-only" not in sys.argv:
-        main()
-    sweeps()
+    if "--levels-only" in sys.argv:
+        sweeps_with_levels()
+    else:
+        if "--sweeps-only" not in sys.argv:
+            main()
+        sweeps()
+        sweeps_with_levels()

@@ -27,9 +27,10 @@ def load(name):
 
 def test_fixture_set_is_complete():
     names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLD, "ref_sweep_*.npz")))
-    assert names == ["ref_sweep_par_f32_l0_w5.npz", "ref_sweep_par_f32_l0_w5_recompute.npz", "ref_sweep_par_i16_l0_w5.npz", "ref_sweep_par_u8_l0_w5.npz",
+    assert names == ["ref_sweep_par_f32_l0_w5.npz", "ref_sweep_par_f32_l0_w5_recompute.npz", "ref_sweep_par_i16_l0_w5.npz",
+                     "ref_sweep_par_lv_f32_l3_w5.npz", "ref_sweep_par_u8_l0_w5.npz",
                      "ref_sweep_seq_alongZ_f32_l1_w7.npz", "ref_sweep_seq_f32_l0_w5.npz", "ref_sweep_seq_f32_l1_w7.npz",
-                     "ref_sweep_seq_i16_l0_w5.npz"]
+                     "ref_sweep_seq_i16_l0_w5.npz", "ref_sweep_seq_lv_f32_l1_w7.npz", "ref_sweep_seq_lv_i16_l1_w7.npz"]
     for n in names:                                   # the outputs are not trivial copies of the inputs
         g = load(n)
         out = g["out"] if "out" in g else g["out_zyx"]
@@ -75,6 +76,58 @@ def test_oracle_integer_wrap_sweeps_equal_par_control_flow(oracle, name, dtype):
     assert g["out_zyx"].dtype == dtype
     assert np.array_equal(oracle.filter_par_integer_input(g["vol"], ks, 0, 5), g["out_zyx"].astype(np.float32))
     assert np.array_equal(oracle.filter_par_integer_input(g["vol"], [ks[0], ks[1], None], 0, 5), g["out_zy"].astype(np.float32))
+
+
+# ---- round 5: real pyramid levels off the Z axis (64 x 64 x 72 volumes: every pass's images keep a coarser level) ----------
+def test_lv_fixtures_really_have_a_level_on_every_axis(oracle):
+    """cv2 keeps level k while both image sides x 0.5^k stay >= 32: on these volumes the result of `-l 1`
+    differs from `-l 0` in every single pass -- the Y and X passes run a pyramid under the reference's control flow."""
+    g = load("ref_sweep_seq_lv_f32_l1_w7.npz")
+    vol = g["vol"][:, :, :]
+    for axis, sigma in enumerate(g["sigmas"]):
+        k = oracle.get_gaussian_kernel(float(sigma))
+        sl = [slice(None)] * 3
+        sl[axis] = slice(20, 20 + k.size + 1)                         # a few targets are enough (and quick)
+        sub = np.ascontiguousarray(vol[tuple(sl)])
+        a = oracle.filter_along_axis(sub, axis, k, 1, 7, vol.mean(), nthreads=8)
+        b = oracle.filter_along_axis(sub, axis, k, 0, 7, vol.mean(), nthreads=8)
+        assert not np.array_equal(a, b), axis
+
+
+def test_oracle_equals_seq_control_flow_with_levels_on_every_axis(oracle):
+    g = load("ref_sweep_seq_lv_f32_l1_w7.npz")
+    ks = [oracle.get_gaussian_kernel(float(s)) for s in g["sigmas"]]
+    assert np.array_equal(oracle.OF_filter(g["vol"], ks, 1, 7, nthreads=8), g["out"])
+    g = load("ref_sweep_seq_lv_i16_l1_w7.npz")
+    assert np.array_equal(oracle.OF_filter_integer_input(g["vol"], ks, 1, 7, nthreads=8), g["out"])
+
+
+def test_oracle_equals_par_control_flow_at_pars_default_levels(oracle):
+    g = load("ref_sweep_par_lv_f32_l3_w5.npz")
+    ks = [oracle.get_gaussian_kernel(float(s)) for s in g["sigmas"]]
+    assert int(g["l"]) == 3
+    assert np.array_equal(oracle.OF_filter(g["vol"], ks, 3, 5, border_mode=1, nthreads=8), g["out_zyx"])
+    assert np.array_equal(oracle.OF_filter(g["vol"], [ks[0], ks[1], None], 3, 5, border_mode=1, nthreads=8), g["out_zy"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ref_sweep_seq_lv_f32_l1_w7.npz", "ref_sweep_seq_lv_i16_l1_w7.npz"])
+def test_hip_equals_seq_control_flow_with_levels_on_every_axis(fdn, name):
+    g = load(name)
+    ks = [fdn.get_gaussian_kernel(float(s)) for s in g["sigmas"]]
+    got = fdn.OF_filter(g["vol"], ks, 1, 7)
+    assert got.dtype == np.float32 and np.array_equal(got, g["out"])
+
+
+@pytest.mark.gpu
+def test_hip_FlowDenoising_at_pars_default_levels(fdn):
+    g = load("ref_sweep_par_lv_f32_l3_w5.npz")
+    ks = [fdn.get_gaussian_kernel(float(s)) for s in g["sigmas"]]
+    for kernels, want in ((ks, g["out_zyx"]), ([ks[0], ks[1], None], g["out_zy"])):
+        vol = g["vol"].copy()
+        fd = fdn.FlowDenoising(3, vol, 3, 5, fdn.get_flow_with_prev_flow, fdn.warp_slice)
+        assert fd.filter(kernels) is None
+        assert np.array_equal(vol, want)
 
 
 # ---- GPU: the HIP path against the same fixtures ---------------------------------------------------------------------------
