@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--engine", choices=("native", "python"), default="native", help="N > 1: fdn_filter_3d_sharded on the native transport "
                     "(libflowdn_rccl.so: RCCL, or shared memory when ranks share a GPU), or the torch.distributed slab engine above the C ABI (distributed.py)")
     ap.add_argument("--path", type=int, default=0, help="fdn_set_option path: 0 auto, 1 staged, 2 per-iteration kernels")
+    ap.add_argument("--two-sided", type=int, default=0, help="fdn_set_option two_sided: both sides of a chain step in one launch, mirror pairs in one workgroup "
+                    "(bit 0: one-iteration kernel, bit 1: 3-iteration kernel); 0 = one launch per side, the product default -- for A/B runs")
     ap.add_argument("--cpu-targets", type=int, default=0, help="target slices of the CPU sample (0 = four per core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check and the sweep-kernel line")
@@ -468,6 +470,7 @@ def run(a, job, fallback):
     h.set_stream(torch.cuda.current_stream().cuda_stream)
     if a.path:
         h.set_option("path", a.path)
+    h.set_option("two_sided", a.two_sided)
 
     eng = None
     out_slab = None
@@ -608,6 +611,8 @@ def run(a, job, fallback):
             res["config"]["workload"] += f"; INTEGER-VOLUME SEMANTICS ({a.integer}) -- not the headline configuration"
     if not a.no_check and not a.integer:
         h.enable_timers(False)
+        h.set_workspace_limit(0)      # gives the handle's buffers back (a limit of 0 is "none"): the check allocates volumes of its own,
+                                      # and on configs[4] the two do not fit side by side
         if world == 1:
             res["checked"] = check_output(h, vol, out, shape, kernels, params, mean)
             if a.levels == 0:

@@ -105,8 +105,14 @@ def _run_single(args, vol, kernels, l, w, device, stats, as_float32, timing=None
     def sink(dtype, st_out):        # the output file, written slab by slab while the rest of the result is still downloading
         stats["streamed"] = True
         return fio.VolumeWriter(args.output, shape, np.float32 if (fio.is_mrc_output(args.output) or tiff32) else dtype, st_out)
+    mapped = None
+    if fio.is_mrc_output(args.output) and not (os.path.exists(args.output) and os.path.exists(args.input) and os.path.samefile(args.input, args.output)):
+        # an MRC output is mapped and made ready (pages faulted in, page-locked where the kernel allows) while the passes run:
+        # the result then lands in the file's own pages in one copy (io.MappedMrcWriter; seq:558-564 writes after the last pass)
+        def mapped():
+            return fio.MappedMrcWriter(args.output, shape)
     return filter_3d_own_mean(vol, kernels, params, device, stats=stats, float32_semantics=as_float32, tiff_downcast=downcast,
-                              timing=timing, sink=sink, wait_for=wait_for)
+                              timing=timing, sink=sink, wait_for=wait_for, mapped_out=mapped)
 
 
 def _reserve(args, shape, dtype, Ks, l, w):

@@ -146,7 +146,7 @@ def _as_f32(vol):
 
 
 def filter_3d_own_mean(vol, kernel, params, device=0, stats=None, float32_semantics=False, tiff_downcast=False, timing=None,
-                       sink=None, wait_for=None):
+                       sink=None, wait_for=None, mapped_out=None):
     """Upload, take vol.mean() (seq:420) on the GPU -- fdn_mean_dev reproduces numpy's float32 reduction bit
     for bit, and a 2 GiB volume costs numpy 0.3 s on the host -- run the passes, download.
     An 8- or 16-bit integer volume travels as it is and becomes float32 on the device (fdn_convert_dev: exact).
@@ -160,6 +160,9 @@ def filter_3d_own_mean(vol, kernel, params, device=0, stats=None, float32_semant
     sink: `sink(dtype, stats_out)` returns an object with write_slab(array) / close() (io.VolumeWriter): the result is
     then downloaded in slabs of Z slices and every slab is handed to it, in order, from a second thread -- the file
     write of one slab overlaps the download of the next (the reference writes after its last pass, seq:558-571).
+    mapped_out: a callable returning an io.MappedMrcWriter (the float32 MRC output file mapped into memory): it is made
+    after the upload (the input may be the same file) and prepared -- pages faulted in and, where allowed, page-locked --
+    in a thread of its own while the passes run; the result is then copied from the GPU straight into the file's pages.
     wait_for: called after the upload and before anything is launched on the process-wide handle -- the CLI passes the
     join of the thread in which that handle reserves its buffers (fdn_reserve_3d); the upload itself then runs on a
     handle of its own, concurrently with it."""
@@ -208,6 +211,7 @@ def filter_3d_own_mean(vol, kernel, params, device=0, stats=None, float32_semant
             if raw_int:
                 h.convert_dev(d_out, src.dtype, d_in, src.size)      # float32 from there into d_in
             lap("h2d")
+            writer = prep = hw = None
             # (statistics from per-slice reductions added in slice order, fdn_stats_slices_dev: the form a multi-GPU run
             # reproduces bit for bit from its slabs, so both write the same header)
             st_in = h.stats_volume(d_in, src.shape) if (stats is not None or params.pad64 != params.pad64) else None
@@ -218,7 +222,22 @@ def filter_3d_own_mean(vol, kernel, params, device=0, stats=None, float32_semant
             # an integer volume's mean is numpy's float64 one (params.pad64); Farneback sees it as float32
             mean = np.float32(params.pad64) if params.warp_mode == _lib.WARP_F64_PADDED else h.mean_dev(d_in, src.size)
             h.filter_3d_dev(d_in, d_out, src.shape, kernel, mean, params)
-            if stats is not None or tiff_downcast:
+            if mapped_out is not None and not tiff_downcast:
+                # The passes are ENQUEUED now (nothing above waits for them) and run for a while on their own: the output
+                # file is mapped and its pages faulted in and page-locked meanwhile.  (Not earlier: hipHostRegister holds a
+                # runtime lock that kernel launches wait for -- started before the launches it added its 0.3 s to the passes.)
+                import threading
+                try:
+                    writer = mapped_out()
+                    hw = _lib.Handle(device)          # page-locking goes through a handle of its own
+                    ready = {}
+                    prep = threading.Thread(target=lambda: ready.setdefault("pinned", writer.prepare(hw)), daemon=True)
+                    prep.start()
+                except OSError:
+                    writer = prep = None
+            if prep is not None:
+                prep.join()                           # (before the statistics' launches: they would queue behind the page-locking)
+            if stats is not None or tiff_downcast or writer is not None:
                 st_out = h.stats_volume(d_out, src.shape)
                 if stats is not None:
                     stats["out"] = st_out
@@ -228,6 +247,25 @@ def filter_3d_own_mean(vol, kernel, params, device=0, stats=None, float32_semant
                 h.truncate_dev(d_out, out.dtype, d_in, src.size)      # the input's device copy is no longer needed
                 d_res = d_in
             lap("compute")
+            if writer is not None:
+                try:
+                    if timing is not None:
+                        timing["out_pinned"] = bool(ready.get("pinned"))
+                    if ready.get("pinned"):
+                        h.d2h(writer.data, d_res)             # one DMA into the file's own pages
+                    else:                                     # pages are there but cannot be locked: slabs through the staging path
+                        per = writer.data[0].nbytes
+                        step = max(1, (128 << 20) // max(per, 1))
+                        for z0 in range(0, src.shape[0], step):
+                            h.d2h(writer.data[z0:z0 + step], d_res + z0 * per)
+                    writer.finish(st_out)
+                    if stats is not None:
+                        stats["streamed"] = True
+                finally:
+                    writer.close()
+                    hw.close()
+                lap("d2h")
+                return None
             pin_out = big and h.host_register(out)
             try:
                 if sink is None:

@@ -15,8 +15,10 @@
  * GaussianBlur/getGaussianKernel, resize, remap) are restated here from their
  * published behaviour.  What IS pinned by reference-generated goldens
  * (tests/golden/): get_gaussian_kernel (seq:30-41) and the no-OF separable sweep
- * (seq:171-192, 290-311, 396-417, 426-431); the rest is pinned by analytic
- * known-answer tests (tests/test_oracle_kat.py).
+ * (seq:171-192, 290-311, 396-417, 426-431), and -- since round 4 -- the control flow of the
+ * sweeps (tests/golden/ref_sweep_*.npz: the reference's own loops run on a cv2 stand-in that
+ * forwards to this file; tests/test_ref_sweeps.py); the two OpenCV routines themselves rest on
+ * analytic known-answer tests (tests/test_oracle.py): "parity unpinned" against cv2.
  *
  * Citations "seq:N" are lines of /root/reference/src/flowdenoising_sequential.py,
  * "par:N" of /root/reference/src/flowdenoising.py.
@@ -978,8 +980,8 @@ static void neighbour(const float* vol, int Z, int Y, int X, int axis, int n, in
  * np.full makes the PADDED volume float64 -- in all three passes, the mean being computed once): Farneback still
  * converts its images to f32 (pad slices become f32(mean)), but cv2.remap of a CV_64F image weights the four taps in
  * double (f32 table weights widened, products and sums in f64, no rounding to f32) and the pad slices hold the f64
- * mean.  The HIP path does not implement this (it pads and remaps in f32); the oracle does, so that a test can
- * bound the difference (tests/test_gpu_full.py::test_integer_input_semantics_bound). */
+ * mean.  The HIP path implements the same semantics (fdn_sweep_params.warp_mode = FDN_WARP_F64_PADDED, fold_warped<1> in
+ * fdn_device.h); tests/test_gpu_integer.py demands bit equality with this restatement. */
 static int g_f64_padded = 0;
 static double g_mean64 = 0.;
 FDO_EXPORT void fdo_set_f64_padded(int on, double mean64) { g_f64_padded = on; g_mean64 = mean64; }

@@ -339,3 +339,43 @@ def test_product_does_not_import_torch():
         assert not bad.search(open(os.path.join(ROOT, "flowdenoising_amd", fn)).read()), fn
     src = open(os.path.join(ROOT, "flowdenoising_amd", "cli.py")).read()
     assert "torch.distributed" not in src.split('"""', 2)[2]        # (the module docstring may say what it no longer does)
+
+
+def test_mapped_mrc_writer_writes_the_file_write_mrc_writes(tmp_path):
+    """io.MappedMrcWriter (the CLI's MRC output: the file mapped, faulted in and -- where allowed -- page-locked while the
+    passes run, the result copied into its pages): byte for byte what write_mrc makes of the same array and statistics,
+    with and without a handle that can page-lock."""
+    from flowdenoising_amd import io as fio
+
+    class NoPin:
+        def host_register(self, a):
+            return False
+
+        def host_unregister(self, a):
+            raise AssertionError("nothing was registered")
+
+    class Pin:
+        def __init__(self):
+            self.live = 0
+
+        def host_register(self, a):
+            assert a.dtype == np.uint8 and a.size == 1024 + 4 * 5 * 33 * 47
+            self.live += 1
+            return True
+
+        def host_unregister(self, a):
+            self.live -= 1
+
+    v = (np.random.default_rng(1).standard_normal((5, 33, 47)) * 10).astype(np.float32)
+    st = fio.volume_stats(v)
+    fio.write_mrc(str(tmp_path / "ref.mrc"), v, stats=st)
+    want = open(tmp_path / "ref.mrc", "rb").read()
+    for name, h in (("a.mrc", NoPin()), ("b.mrc", Pin())):
+        w = fio.MappedMrcWriter(str(tmp_path / name), v.shape)
+        assert w.prepare(h) == isinstance(h, Pin)
+        assert w.data.shape == v.shape and w.data.flags["C_CONTIGUOUS"] and w.data.flags["WRITEABLE"]
+        w.data[...] = v
+        w.finish(st)
+        w.close()                                   # a second close is harmless
+        assert open(tmp_path / name, "rb").read() == want
+        assert getattr(h, "live", 0) == 0
