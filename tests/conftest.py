@@ -51,3 +51,32 @@ def assert_kernel(k, ref, sigma):
         assert np.abs(k - ref).max() <= np.spacing(ref.max()) and np.count_nonzero(k != ref) <= 2
     else:
         assert np.array_equal(k, ref)
+
+
+@pytest.fixture(autouse=True)
+def _resource_trace(request):
+    """FDN_TEST_TRACE=<file>: one line per test with the process's open file descriptors, threads and resident memory
+    (a diagnostic for failures that depend on what earlier tests left behind; off by default)."""
+    path = os.environ.get("FDN_TEST_TRACE")
+    if not path:
+        yield
+        return
+    import resource
+    import threading
+
+    def snap(tag):
+        try:
+            nfd = len(os.listdir("/proc/self/fd"))
+        except OSError:
+            nfd = -1
+        rss = 0
+        try:
+            with open("/proc/self/statm") as f:
+                rss = int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") >> 20
+        except (OSError, ValueError):
+            pass
+        with open(path, "a") as f:
+            f.write(f"{tag} {request.node.nodeid} fds={nfd}/{resource.getrlimit(resource.RLIMIT_NOFILE)[0]} threads={threading.active_count()} rss={rss}MiB\n")
+    snap("begin")
+    yield
+    snap("end")

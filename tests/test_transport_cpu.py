@@ -133,3 +133,61 @@ def test_an_aborting_rank_stops_the_waiting_ones(fdn, tmp_path):
     for th in ths:
         th.join(timeout=60)
     assert "another rank failed" in out["waiter"] and time.perf_counter() - t0 < 30
+
+
+def _supervised(tmp_path, child_code, world=2, extra_env=None, port=29876):
+    """`world` processes with torch.distributed.run's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT, a common
+    parent), each supervising one child that runs `child_code`; returns their (exit code, stdout) pairs."""
+    sup = ("import sys, json; sys.path.insert(0, %r)\n"
+           "from flowdenoising_amd import launch\n"
+           "job = launch.job()\n"
+           "assert launch.started_by_torchrun()\n"
+           "rc, why = launch.supervise_rank([sys.executable, '-c', %r], job, relay=lambda ln: sys.stdout.write('child: ' + ln))\n"
+           "print(json.dumps({'rank': job[0], 'rc': rc, 'why': why}))\n"
+           "if job[0] == 0: launch.remove_derived_rendezvous(job[3])\n") % (ROOT, child_code)
+    procs = []
+    for r in range(world):
+        env = {k: v for k, v in os.environ.items() if k not in ("FDN_RANK", "FDN_WORLD", "FDN_RDV")}
+        env.update(RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_PORT=str(port), FDN_RDV_TIMEOUT="30")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, "-c", sup], env=env, stdout=subprocess.PIPE, text=True))
+    return [(p.wait(timeout=120), p.stdout.read()) for p in procs]
+
+
+def test_supervised_native_ranks_under_a_torchrun_like_parent(fdn, tmp_path):
+    """launch.supervise_rank: a rank that torch.distributed.run started runs its native rank in ONE child (FDN_RANK / FDN_WORLD /
+    FDN_RDV set, the torchrun variables gone) and relays rank 0's output; all children meet in the directory every supervisor
+    derives from the common parent."""
+    import json
+    child = ("import os, sys; sys.path.insert(0, %r)\n"
+             "from flowdenoising_amd import _lib, launch\n"
+             "assert 'RANK' not in os.environ and not launch.started_by_torchrun()\n"
+             "r, w, l, rdv = launch.job()\n"
+             "t = _lib.Transport('shm', r, w, -1, rdv)\n"
+             "assert t.count() == w\n"
+             "t.barrier(); t.close()\n"
+             "print('rank', r, 'of', w, 'ok')\n") % ROOT
+    res = _supervised(tmp_path, child)
+    recs = [json.loads(out.strip().splitlines()[-1]) for _, out in res]
+    assert [r["rc"] for r in recs] == [0, 0] and all(code == 0 for code, _ in res)
+    assert "child: rank 0 of 2 ok" in res[0][1] and "child:" not in res[1][1]
+
+
+def test_a_failed_native_rank_ends_every_supervised_rank_with_the_reason(fdn, tmp_path):
+    """Rank 1's native child gives up (report_failure + exit code 3) while rank 0's waits at a barrier with a long timeout:
+    rank 0's supervisor sees error.1 in the shared directory, ends its own child, and both supervisors return the reason --
+    promptly, and still fresh for another engine."""
+    import json
+    import time
+    child = ("import os, sys, time; sys.path.insert(0, %r)\n"
+             "from flowdenoising_amd import _lib, launch\n"
+             "r, w, l, rdv = launch.job()\n"
+             "if r == 1:\n"
+             "    launch.report_failure(rdv, r, 'RuntimeError: no links today'); sys.exit(3)\n"
+             "time.sleep(300)\n") % ROOT
+    t0 = time.perf_counter()
+    res = _supervised(tmp_path, child, port=29877)
+    assert time.perf_counter() - t0 < 60
+    recs = [json.loads(out.strip().splitlines()[-1]) for _, out in res]
+    assert all(r["rc"] != 0 for r in recs)
+    assert all(any("no links today" in w for w in r["why"]) for r in recs), recs

@@ -19,6 +19,6 @@ if [ "$CFG4_PMC" = 1 ]; then
     timeout -k 10 400 rocprofv3 --pmc $set --output-format csv -d gpurun_out/cfg4_pmc$i -- $B > gpurun_out/cfg4_pmc$i.log 2>&1 || { echo "cfg4 set $i failed"; break; }
   done
   python3 tools/make_traffic_json.py "k_farneback_iter<7" gpurun_out/cfg4_traffic.json ${1:-unknown} "gpurun_out/cfg4_pmc*/**/*_counter_collection.csv" 3 15 512,2048,2048 2,2,4 " --shape 512,2048,2048 --sigmas 2,2,4 --levels 3 --winsize 15"
-  cp gpurun_out/cfg4_traffic.json profiles/r04_cfg4_traffic.json
+  cp gpurun_out/cfg4_traffic.json profiles/${ROUND:-r05}_cfg4_traffic.json
   timeout -k 10 900 python bench.py --shape 512,2048,2048 --sigmas 2,2,4 --levels 3 --winsize 15 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/cfg4_bench.json 2> gpurun_out/cfg4_bench.err; cut -c1-200 gpurun_out/cfg4_bench.json
 fi
