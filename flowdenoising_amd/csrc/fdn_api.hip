@@ -4,8 +4,10 @@
 #include "../../include/flowdn.h"
 #include "fdn_internal.h"
 
+#include <fcntl.h>
 #include <math.h>
 #include <stdarg.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -170,7 +172,26 @@ struct fdn_ctx {
     struct Stamp { hipEvent_t a, b; int which; };
     std::vector<Stamp> stamps;        // recorded, not yet resolved
     std::vector<hipEvent_t> ev_pool;  // free events
+    int trace_fd = -1;                // FDN_LAUNCH_TRACE=<file>: every stage of the per-stage / pyramid paths is named there before it
+                                      // is launched and waited for afterwards -- a GPU fault then has a last line (diagnostic only)
 };
+
+// Diagnostic: name the stage that is about to run (and wait for everything before it), so that an abort of the runtime --
+// a memory fault of a kernel is reported asynchronously, without the kernel's name -- can be attributed.
+static void trace_point(fdn_ctx* h, const char* fmt, ...)
+{
+    if (h->trace_fd < 0) return;
+    (void)hipStreamSynchronize(h->stream);
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    int n = vsnprintf(buf, sizeof buf - 1, fmt, ap);
+    va_end(ap);
+    if (n < 0) return;
+    if (n > (int)sizeof buf - 2) n = (int)sizeof buf - 2;
+    buf[n++] = '\n';
+    (void)!write(h->trace_fd, buf, (size_t)n);
+}
 
 static hipEvent_t get_event(fdn_ctx* h)
 {
@@ -438,6 +459,7 @@ static int build_R_pyramid(fdn_ctx* h, const float* imgs, int nimg, int H, int W
     float* small = blurred + (size_t)chunk * HW;
     ScopedTimer t(h, FDN_TIMER_POLYEXP);
     for (size_t k = 1; k < lv.size(); k++) {
+        trace_point(h, "build_R_pyramid level %zu: %d images %dx%d -> %dx%d, blur %d taps", k, nimg, W, H, lv[k].w, lv[k].h, lv[k].smooth_sz);
         if (lv[k].smooth_sz > FDN_MAX_BLUR_TAPS) return fail("pyramid level %zu needs a %d-tap blur (max %d)", k, lv[k].smooth_sz, FDN_MAX_BLUR_TAPS);
         BlurTaps bt;
         prepare_blur_taps(lv[k].smooth_sz, lv[k].sigma, &bt);
@@ -465,6 +487,7 @@ static int run_iterations(fdn_ctx* h, const float* Rstack, const float* flow_in,
     if (h->tn.strict_order && !strict_order_supported(W, winsize))
         return fail("strict order was requested, but a row of %d columns (winsize %d) does not fit the 160 KB of LDS "
                     "its serial running sum needs; strict mode never falls back silently", W, winsize);
+    trace_point(h, "run_iterations %dx%d npairs %d t0 %d d %d winsize %d: update_matrices", W, H, pb.npairs, pb.t0, pb.d, winsize);
     {
         ScopedTimer t(h, FDN_TIMER_UPDATE_MATRICES);
         launch_update_matrices(Rstack, flow_in, M0, pb, H, W, h->stream);
@@ -477,6 +500,7 @@ static int run_iterations(fdn_ctx* h, const float* Rstack, const float* flow_in,
     float* cur = M0; float* nxt = M1;
     for (int it = 0; it < iters; it++) {
         bool update = it < iters - 1;
+        trace_point(h, "  update_flow it %d (%s)", it, h->tn.strict_order ? "strict" : "scan");
         ScopedTimer t(h, FDN_TIMER_UPDATE_FLOW);
         if (h->tn.strict_order) {
             if (!launch_update_flow_strict(Rstack, cur, update ? nxt : nullptr, flow, pb, H, W, winsize, h->stream))
@@ -499,6 +523,7 @@ static int pyramid_batch(fdn_ctx* h, const std::vector<PyrLevel>& lv, const floa
     float* fp = (float*)h->flow_pyr.p;
     const int n = pb.npairs;
     float* fl = fp + lv[L].f_off;
+    trace_point(h, "pyramid_batch %dx%d levels %d n %d initial %d", W, H, L, n, (int)has_initial);
     if (has_initial) {
         if (resize_dev(h, flow_init, H, W, fl, lv[L].h, lv[L].w, 2, n, 3, true, lv[L].scale)) return -1;
     } else {
@@ -506,6 +531,7 @@ static int pyramid_batch(fdn_ctx* h, const std::vector<PyrLevel>& lv, const floa
     }
     for (int k = L; k >= 0; k--) {
         float* cur = k == 0 ? flow_full : fp + lv[k].f_off;
+        trace_point(h, " level %d: %dx%d%s", k, lv[k].w, lv[k].h, k < L ? ", upsample the coarser flow" : "");
         if (k < L)
             if (resize_dev(h, fp + lv[k + 1].f_off, lv[k + 1].h, lv[k + 1].w, cur, lv[k].h, lv[k].w, 2, n, 1, true, 2.0)) return -1;
         const float* Rk = k == 0 ? R0 : (const float*)h->Rpyr.p + lv[k].r_off;
@@ -804,6 +830,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
     out = out_all + (size_t)cr0 * HW;
     WarpMode wm = wm_all;
     wm.pad_lo = std::max(0, wm_all.pad_lo - cr0); wm.pad_hi = wm_all.pad_hi - cr0;
+    trace_point(h, "sweep_stack S %d %dx%d K %d path %d levels %zu: polyexp of %d slices", S, W, H, K, path, lv.size() - 1, nr + 2 * r);
     {
         ScopedTimer t(h, FDN_TIMER_POLYEXP);
         launch_blur3_polyexp(stack, R, nr + 2 * r, H, W, pc, st);
@@ -886,6 +913,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
                     if (pyramid_batch(h, lv, R, fprev, fcur, M0, M1, pb, H, W, p->winsize, p->iters)) return -1;
                 } else if (run_iterations(h, R, fprev, fcur, M0, M1, pb, H, W, p->winsize, p->iters)) return -1;
             }
+            trace_point(h, "sweep_side %d", side);
             {
                 ScopedTimer t(h, FDN_TIMER_WARP);
                 std::vector<double> wts(r);
@@ -901,6 +929,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
     }
     }   // batches of R
     if (wm_all.kind == FDN_WARP_ROUND_INT) launch_trunc_clamp(out_all, (size_t)S * HW, wm_all.lo, wm_all.hi, st);   // par:131, 287: the integer volume takes the pass
+    trace_point(h, "sweep_stack done");
     FDN_HIP(hipGetLastError());
     return 0;
 }
@@ -1360,6 +1389,7 @@ FDN_API int fdn_create(int device, fdn_handle* out)
     h->tn.fused_occ = env_int("FDN_FUSED_OCC");
     h->tn.lds_pad = (unsigned)env_int("FDN_LDS_PAD");
     if (getenv("FDN_TWO_SIDED")) h->tn.two_sided = env_int("FDN_TWO_SIDED") & 3;
+    if (const char* tp = getenv("FDN_LAUNCH_TRACE")) h->trace_fd = open(tp, O_CREAT | O_WRONLY | O_APPEND, 0644);
     *out = h;
     return 0;
 }
@@ -1374,6 +1404,7 @@ FDN_API int fdn_destroy(fdn_handle h)
     resolve_stamps(h);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->trace_fd >= 0) close(h->trace_fd);
     delete h;
     return 0;
 }

@@ -75,8 +75,17 @@ def _resource_trace(request):
                 rss = int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") >> 20
         except (OSError, ValueError):
             pass
+        gpu = ""
+        try:                                    # device memory: free / total, and what the process-wide handle holds
+            from flowdenoising_amd import operators
+            if operators._handles:
+                h = next(iter(operators._handles.values()))
+                fre, tot = h.mem_info()
+                gpu = f" gpu_free={fre >> 20}MiB/{tot >> 20}MiB handle={h.workspace_bytes() >> 20}MiB"
+        except Exception as e:                  # noqa: BLE001 -- a diagnostic must not fail a test
+            gpu = f" gpu=? ({type(e).__name__})"
         with open(path, "a") as f:
-            f.write(f"{tag} {request.node.nodeid} fds={nfd}/{resource.getrlimit(resource.RLIMIT_NOFILE)[0]} threads={threading.active_count()} rss={rss}MiB\n")
+            f.write(f"{tag} {request.node.nodeid} fds={nfd}/{resource.getrlimit(resource.RLIMIT_NOFILE)[0]} threads={threading.active_count()} rss={rss}MiB{gpu}\n")
     snap("begin")
     yield
     snap("end")
