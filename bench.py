@@ -362,6 +362,7 @@ def check_sharded(h, move, dev, rank, world, shape, kernels, params, amplitude, 
     # the volume the ranks filtered: the generator seeds a slab's noise by its first slice, so the whole is their concatenation
     vol = torch.cat([synth.make_volume(shape, seed=1234 + 3, amplitude=amplitude, xp=torch, device=dev, z0=z0, zlen=z1 - z0) for z0, z1 in parts])
     single = torch.empty_like(vol)
+    torch.cuda.synchronize()
     mean = h.mean_dev(vol.data_ptr(), vol.numel())
     h.filter_3d_dev(vol.data_ptr(), single.data_ptr(), shape, kernels, mean, params)
     torch.cuda.synchronize()
@@ -474,7 +475,11 @@ def run(a, job, fallback):
         params.border_mode, params.warp_mode, params.round_lo, params.round_hi = _lib.BORDER_WRAP, _lib.WARP_ROUND_INT, -32768.0, 32767.0
 
     h = _lib.Handle(device)
-    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    if tr is None:
+        h.set_stream(torch.cuda.current_stream().cuda_stream)
+    # (the native N > 1 engine keeps the handle's own non-blocking stream, as the CLI's ranks and the RCCL tests do: the
+    #  exchanges then never sit on the legacy default stream; torch only generates the input, with a device-wide
+    #  synchronisation on either side of the timed region)
     if a.path:
         h.set_option("path", a.path)
     h.set_option("two_sided", a.two_sided)
@@ -541,6 +546,7 @@ def run(a, job, fallback):
             return np.stack([r.cpu().numpy() for r in allr])
         return arr[None]
 
+    torch.cuda.synchronize()          # the generator's kernels (torch's stream) before the library's own stream reads the volume
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
