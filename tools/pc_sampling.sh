@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out; rm -rf /tmp/pcs
 ARGS=${@:---shape 96,1024,1024 --axes z --levels 0 --winsize 15}
 UNIT=cycles; IVAL=1048576
-if [ "$METHOD" = host_trap ]; then UNIT=time; IVAL=100; fi
+if [ "$METHOD" = host_trap ]; then UNIT=time; IVAL=1000; fi
 export ROCPROFILER_PC_SAMPLING_BETA_ENABLED=1
 timeout -k 10 170 rocprofv3 --pc-sampling-beta-enabled --pc-sampling-method $METHOD --pc-sampling-unit $UNIT --pc-sampling-interval $IVAL --kernel-trace --output-format csv -d /tmp/pcs -- python3 bench.py $ARGS --steps 1 --warmup 0 --no-cpu-baseline --no-timers --no-check > gpurun_out/pcs_$METHOD.log 2>&1
 echo "rocprofv3 rc=$?"; tail -3 gpurun_out/pcs_$METHOD.log | cut -c1-200
