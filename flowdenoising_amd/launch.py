@@ -129,7 +129,7 @@ def supervise_rank(argv, job, relay=None, deadline=None):
     if deadline is None:
         deadline = float(os.environ.get("FDN_NATIVE_DEADLINE", "900"))
     env = dict(os.environ, FDN_RANK=str(rank), FDN_WORLD=str(world), FDN_RDV=rdv, FDN_LOCAL_RANK=str(local))
-    env.setdefault("FDN_RDV_TIMEOUT", "180")
+    env.setdefault("FDN_RDV_TIMEOUT", "300")      # ranks reach their rendezvous a first `import torch` apart (minutes on a fresh box)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK"):
         env.pop(k, None)
     child = subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=(rank == 0))
