@@ -407,15 +407,24 @@ def main():
             raise
         if job is None:
             raise
+        import signal
         import traceback
         traceback.print_exc()
         launch.report_failure(job[3], job[0], f"{type(e).__name__}: {e}")
-        tr = _live.get("tr")
+        # leave in an orderly way -- transport, handle, then the interpreter's own teardown (torch's context) -- but under an
+        # alarm: a communicator whose peers are gone may never come back from its teardown, and then the default action of
+        # SIGALRM ends the process
+        signal.alarm(20)
+        tr = _live.pop("tr", None)
         if tr is not None:
             tr.abort()
+            tr.close()
+        h = _live.pop("h", None)
+        if h is not None:
+            h.close()
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(1)                 # no destructors: a communicator whose peers are gone may never come back from its teardown
+        sys.exit(1)
 
 
 _live = {}                          # the rank's transport, for the failure path above
@@ -475,6 +484,7 @@ def run(a, job, fallback):
         params.border_mode, params.warp_mode, params.round_lo, params.round_hi = _lib.BORDER_WRAP, _lib.WARP_ROUND_INT, -32768.0, 32767.0
 
     h = _lib.Handle(device)
+    _live["h"] = h
     if tr is None:
         h.set_stream(torch.cuda.current_stream().cuda_stream)
     # (the native N > 1 engine keeps the handle's own non-blocking stream, as the CLI's ranks and the RCCL tests do: the

@@ -15,6 +15,30 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _starts_gpu_processes(item):
+    """A GPU test that runs other GPU processes (the CLI, bench.py, rank processes of the transports)."""
+    if item.get_closest_marker("gpu") is None:
+        return False
+    try:
+        import inspect
+        src = inspect.getsource(item.function)
+    except (OSError, TypeError, AttributeError):
+        return False
+    return "subprocess." in src or "launch.spawn" in src
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests that start other GPU processes run LAST, in their own order.  Round 5: in 5 of 12 full `-m gpu` sessions the
+    HIP runtime aborted the interpreter at the first in-process GPU call that followed a stretch of such tests (never in the 8
+    sessions that left them out, never in a short session) -- what the runtime objects to when a process goes back to its GPU
+    after others have used it is not known (profiles/history/NOTES_r05.md, section 5); with this order the in-process tests
+    have all run by then."""
+    tail = [it for it in items if _starts_gpu_processes(it)]
+    if tail:
+        ids = {id(it) for it in tail}
+        items[:] = [it for it in items if id(it) not in ids] + tail
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure only)."""

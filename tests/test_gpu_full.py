@@ -657,11 +657,9 @@ def test_strict_order_on_rows_of_2048_pixels_and_more(fdn, oracle, tmp_path, sha
     value stays in a register, one segment of window sums in LDS at a time), so OpenCV's own f64 order can be verified on
     them too -- until round 4 the mode refused rows wider than about 2040.  Z pass, every slice compared with the
     OpenCV-order oracle bit for bit.
-    Runs in a process of its own, like the strict test above (round 5): on 2048-pixel rows the serial kernel takes a CU's
-    whole 160 KB of LDS for milliseconds per launch, and in 2 of 10 full-suite runs of round 5 the runtime aborted the
-    interpreter inside this call -- only ever here, only after 80 other tests in one process, never alone
-    (profiles/history/NOTES_r05.md, section 5).  A fresh process keeps such an abort from taking the session down with it;
-    the comparison is as strict as before."""
+    Runs in a process of its own, like the strict test above (round 5: the HIP runtime aborted the interpreter inside this call in
+    3 of 13 long sessions -- profiles/history/NOTES_r05.md, section 5 -- and a fresh process keeps such an abort from taking the
+    session down with it; the comparison is as strict as before)."""
     from flowdenoising_amd.synth import make_volume
     vol = make_volume(shape, seed=77, amplitude=100.0)
     np.save(tmp_path / "v.npy", vol)
