@@ -164,18 +164,13 @@ __global__ __launch_bounds__((ACC ? 192 : 128) * (TWO ? 2 : 1)) void k_farneback
         // Deeper pipelines measured: two steps for the flow / R0
         // loads, four sets: the same time; two steps per hop, five sets: 164-196 VGPRs, two waves per SIMD, 10 % slower.)
         struct RowOps { float2 f; fdn_v2f r01, r23; float r4; int x1, y1; float fx, fy; GatherTapsP g; };
-#ifndef FDN_ITER_FAKE_ROWS
-#define FDN_ITER_FAKE_ROWS 0      // timing experiment only (wrong results): 1 = every row's operands come from rows 0-7 (cache-resident)
-#endif
         auto load_ops = [&](int row, RowOps& o) __attribute__((always_inline)) {
             row = row < H ? row : H - 1;
-            if (FDN_ITER_FAKE_ROWS) row &= 7;
             o.f = load_flow(row);
             load_R(R0i, (unsigned)row * (unsigned)W + (unsigned)xc, o.r01, o.r23, o.r4);
         };
         auto gather_ops = [&](int row, RowOps& o) __attribute__((always_inline)) {
             row = row < H ? row : H - 1;
-            if (FDN_ITER_FAKE_ROWS) row &= 7;
             flow_target(xf, (float)row, o.f.x, o.f.y, o.x1, o.y1, o.fx, o.fy);
             gather_R1_p(R1i, H, W, o.x1, o.y1, o.g);
         };
