@@ -24,15 +24,16 @@ def _starts_gpu_processes(item):
         src = inspect.getsource(item.function)
     except (OSError, TypeError, AttributeError):
         return False
-    return "subprocess." in src or "launch.spawn" in src
+    return "subprocess." in src or "launch.spawn" in src or "run_in_fresh_process" in src
 
 
 def pytest_collection_modifyitems(config, items):
-    """GPU tests that start other GPU processes run LAST, in their own order.  Round 5: in 5 of 12 full `-m gpu` sessions the
-    HIP runtime aborted the interpreter at the first in-process GPU call that followed a stretch of such tests (never in the 8
-    sessions that left them out, never in a short session) -- what the runtime objects to when a process goes back to its GPU
-    after others have used it is not known (profiles/history/NOTES_r05.md, section 5); with this order the in-process tests
-    have all run by then."""
+    """GPU tests that start other GPU processes run LAST, in their own order, and GPU work that is multi-threaded runs in
+    processes of its own (run_in_fresh_process).  Round 5: in 6 of 19 full `-m gpu` sessions the HIP runtime aborted the
+    interpreter inside an ordinary in-process call, each time one to three tests after work of that kind -- the out-of-core
+    mode's worker threads, rank threads, rank processes -- and never in a short session or one without them; what the runtime
+    objects to is not known (profiles/history/NOTES_r05.md, section 5).  The long-lived test process now only ever does
+    single-threaded GPU work, and all of it before the first other GPU process starts."""
     tail = [it for it in items if _starts_gpu_processes(it)]
     if tail:
         ids = {id(it) for it in tail}
@@ -53,6 +54,25 @@ def fdn():
     import flowdenoising_amd
     flowdenoising_amd._lib.load()
     return flowdenoising_amd
+
+
+def run_in_fresh_process(code, arrays, tmp_path, timeout=600, env=None):
+    """Run `code` (Python source) in a process of its own with the arrays of `arrays` (a dict) loaded as variables of the same
+    names; the script puts what it wants to hand back into a dict called `out` (name -> array), which is returned.
+    For GPU work that is multi-threaded (the out-of-core mode's workers, rank threads): round 5's long sessions showed the
+    HIP runtime aborting the interpreter some tests AFTER such work had run in the pytest process itself
+    (profiles/history/NOTES_r05.md, section 5); the long-lived test process therefore stays single-threaded on the GPU."""
+    import subprocess
+    import numpy as np
+    np.savez(tmp_path / "fresh_in.npz", **{k: np.asarray(v) for k, v in arrays.items()})
+    script = ("import sys, numpy as np\nsys.path.insert(0, %r)\nsys.path.insert(0, %r)\n"
+              "_in = np.load(%r, allow_pickle=False)\n"
+              "globals().update({k: _in[k] for k in _in.files})\nout = {}\n" % (ROOT, os.path.join(ROOT, "tests"), str(tmp_path / "fresh_in.npz"))
+              + code + "\nnp.savez(%r, **out)\n" % str(tmp_path / "fresh_out.npz"))
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=timeout, env={**os.environ, **(env or {})})
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(tmp_path / "fresh_out.npz", allow_pickle=False)
+    return {k: got[k] for k in got.files}, r.stdout
 
 
 def rel_err(a, b):

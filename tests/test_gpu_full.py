@@ -614,16 +614,21 @@ def test_non_finite_voxels_do_not_derail_the_kernels(fdn):
 
 
 @pytest.mark.parametrize("l,border,chunk", [(0, 0, 3), (1, 0, 4), (0, 1, 5), (0, 0, None)])
-def test_streamed_filter_equals_resident_filter(fdn, l, border, chunk):
+def test_streamed_filter_equals_resident_filter(fdn, tmp_path, l, border, chunk):
     """Out-of-core mode (volume on the host, chunks of a pass's slices on the GPU): bit-identical to the
-    resident OF_filter, with mean-padded and wrap-around volume ends, with a pyramid, and for no_OF."""
-    from flowdenoising_amd import streaming
+    resident OF_filter, with mean-padded and wrap-around volume ends, with a pyramid, and for no_OF.
+    (The streamed runs -- worker threads with handles of their own -- happen in a fresh process: conftest.run_in_fresh_process.)"""
+    from conftest import run_in_fresh_process
     vol = _vol((11, 70, 90), seed=17)
     ks = [fdn.get_gaussian_kernel(1.0), fdn.get_gaussian_kernel(0.5), fdn.get_gaussian_kernel(1.5)]
     want = fdn.OF_filter(vol, ks, l, 5, border_mode=border)
-    got = streaming.OF_filter_streamed(vol, ks, l, 5, chunk, border_mode=border)
-    assert np.array_equal(got, want)
-    assert np.array_equal(streaming.no_OF_filter_streamed(vol, ks, chunk), fdn.no_OF_filter(vol, ks))
+    code = ("from flowdenoising_amd import streaming\n"
+            "ks = [k0, k1, k2]\nchunk = None if int(chunk) < 0 else int(chunk)\n"
+            "out['of'] = streaming.OF_filter_streamed(vol, ks, int(l), 5, chunk, border_mode=int(border))\n"
+            "out['no_of'] = streaming.no_OF_filter_streamed(vol, ks, chunk)\n")
+    got, _ = run_in_fresh_process(code, dict(vol=vol, k0=ks[0], k1=ks[1], k2=ks[2], l=l, border=border, chunk=-1 if chunk is None else chunk), tmp_path)
+    assert np.array_equal(got["of"], want)
+    assert np.array_equal(got["no_of"], fdn.no_OF_filter(vol, ks))
 
 
 def test_strict_order_mode_reproduces_opencvs_horizontal_running_sum(oracle, tmp_path):
@@ -805,24 +810,31 @@ def _write_mrc_any(path, vol):
     (8, (17, 40, 72), "1.0,0.5,1.0", 0, 0, 5, np.int16),         # seq on an integer volume: the float64 padded volume through every exchange
     (7, (15, 64, 66), "0.5,1.0,1.0", 1, 0, 15, np.int16),        # par on an integer volume, the one-iteration kernel
 ])
-def test_native_engine_world_7_and_8_as_rank_threads(fdn, world, shape, sig, border, l, w, dtype):
+def test_native_engine_world_7_and_8_as_rank_threads(fdn, tmp_path, world, shape, sig, border, l, w, dtype):
     """fdn_filter_3d_sharded -- plan, packing, one exchange per pass, the exact mean, the passes -- at world = 7 and 8 on one
     GPU: every rank a thread with its own handle, stream and shared-memory transport (tests/_thread_ranks.py); the
     concatenated slabs equal the single-GPU OF_filter bit for bit.  (src/flowdenoising.py:181-206 is the decomposition this
-    replaces; the driver's 8-GPU box runs the same engine over RCCL.)"""
-    import _thread_ranks
-    from flowdenoising_amd import _lib, operators
+    replaces; the driver's 8-GPU box runs the same engine over RCCL.)  The rank threads live in a fresh process
+    (conftest.run_in_fresh_process); the single-GPU reference is computed here."""
+    import json
+    from conftest import run_in_fresh_process
+    from flowdenoising_amd import _lib
     vol = _vol(shape, seed=41)
     if dtype is not np.float32:
         vol = np.round((vol - vol.min()) * (3000.0 / (vol.max() - vol.min())) - 700).astype(dtype)
     ks = [None if s == "-" else fdn.get_gaussian_kernel(float(s)) for s in sig.split(",")]
     want = fdn.OF_filter(vol, ks, l, w, border_mode=border)
-    p = operators.integer_semantics(vol, operators._params(l, w, True, border, True))
-    got, info = _thread_ranks.run(vol.astype(np.float32), ks, p, world)
+    code = ("import json, _thread_ranks\n"
+            "from flowdenoising_amd import _lib, operators\n"
+            "ks = [None if s == '-' else _lib.gaussian_kernel(float(s)) for s in str(sig).split(',')]\n"
+            "p = operators.integer_semantics(vol, operators._params(int(l), int(w), True, int(border), True))\n"
+            "got, info = _thread_ranks.run(vol.astype(np.float32), ks, p, int(world))\n"
+            "out['got'] = got\nprint('INFO ' + json.dumps(info))\n")
+    res, stdout = run_in_fresh_process(code, dict(vol=vol, sig=sig, l=l, w=w, border=border, world=world), tmp_path)
+    info = json.loads([ln for ln in stdout.splitlines() if ln.startswith("INFO ")][-1][5:])
     print(info)
     assert info["count"] == world and len(info["devices"]) == world and len(set(info["devices"])) == 1      # one GPU: a rehearsal, and it says so
-    if border == _lib.BORDER_WRAP and dtype is not np.float32:
-        want = want.astype(np.float32)          # par keeps the integer dtype on the host side; the engine's slabs are float32 holding integers
+    got = res["got"]
     assert got.dtype == np.float32 and np.array_equal(got, want.astype(np.float32))
 
 

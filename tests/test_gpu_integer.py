@@ -63,9 +63,10 @@ def test_seq_semantics_on_every_path_and_no_of(fdn, oracle):
     assert not np.array_equal(one, fdn.OF_filter_along_Z(f32, ks[0], 0, 5, np.float32(m64)))
 
 
-def test_seq_semantics_chunked_and_streamed(fdn, oracle):
-    """The pad slices of every chunk are found again when a workspace limit cuts the passes, and in the out-of-core mode."""
-    from flowdenoising_amd import streaming
+def test_seq_semantics_chunked_and_streamed(fdn, oracle, tmp_path):
+    """The pad slices of every chunk are found again when a workspace limit cuts the passes, and in the out-of-core mode
+    (whose worker threads run in a fresh process: conftest.run_in_fresh_process)."""
+    from conftest import run_in_fresh_process
     from flowdenoising_amd.operators import handle
     vol = _int_vol((13, 64, 72), 13, np.uint16)
     ks = [fdn.get_gaussian_kernel(s) for s in (1.5, 1.0, 1.0)]
@@ -77,8 +78,11 @@ def test_seq_semantics_chunked_and_streamed(fdn, oracle):
         assert np.array_equal(fdn.OF_filter(vol, ks, 1, 5), want)
     finally:
         h.set_workspace_limit(0)
-    assert np.array_equal(streaming.OF_filter_streamed(vol, ks, 1, 5, 4), want)
-    assert np.array_equal(streaming.no_OF_filter_streamed(vol, ks, 3), fdn.no_OF_filter(vol, ks))
+    code = ("from flowdenoising_amd import streaming\nks = [k0, k1, k2]\n"
+            "out['of'] = streaming.OF_filter_streamed(vol, ks, 1, 5, 4)\nout['no_of'] = streaming.no_OF_filter_streamed(vol, ks, 3)\n")
+    got, _ = run_in_fresh_process(code, dict(vol=vol, k0=ks[0], k1=ks[1], k2=ks[2]), tmp_path)
+    assert np.array_equal(got["of"], want)
+    assert np.array_equal(got["no_of"], fdn.no_OF_filter(vol, ks))
 
 
 def test_seq_semantics_slab_engine(fdn, oracle):
