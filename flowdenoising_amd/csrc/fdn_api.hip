@@ -13,6 +13,7 @@
 #include <string.h>
 #include <algorithm>
 #include <array>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -144,6 +145,14 @@ void prepare_blur_taps(int n, double sigma, BlurTaps* bt)
 
 using namespace fdn;
 
+// Device-wide operations of the runtime -- allocating, freeing (hipFree waits for the whole device), creating and destroying
+// streams and events -- are taken one at a time across the handles of a process.  Handles are per host thread (par calls its
+// pair operators from P threads, par:187-193; the out-of-core mode has worker threads with handles of their own), and in round
+// 5 long sessions that had created and destroyed handles in several threads at once saw the runtime abort some calls later
+// (profiles/history/NOTES_r05.md, section 5).  These calls are rare and slow; the lock costs nothing measurable.
+static std::recursive_mutex g_device_wide;
+#define FDN_DEVICE_WIDE std::lock_guard<std::recursive_mutex> device_wide_guard_(g_device_wide)
+
 // ---- handle -----------------------------------------------------------------------
 struct DevBuf {
     void* p = nullptr;
@@ -198,6 +207,7 @@ static hipEvent_t get_event(fdn_ctx* h)
 {
     if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
+    FDN_DEVICE_WIDE;
     (void)hipEventCreate(&e);
     return e;
 }
@@ -227,8 +237,9 @@ static int ensure(fdn_ctx* h, DevBuf& b, size_t bytes)
     const bool oversized = h->ws_limit ? b.cap > bytes + bytes / 4 + std::min<size_t>((size_t)16 << 20, h->ws_limit >> 8)
                                        : (b.cap / 4 > bytes && b.cap - bytes > ((size_t)1 << 30));
     if (b.cap >= bytes && !oversized) return 0;
+    if (b.p) FDN_HIP(hipStreamSynchronize(h->stream));
+    FDN_DEVICE_WIDE;
     if (b.p) {
-        FDN_HIP(hipStreamSynchronize(h->stream));
         FDN_HIP(hipFree(b.p));
         b.p = nullptr; b.cap = 0;
     }
@@ -240,6 +251,7 @@ static int ensure(fdn_ctx* h, DevBuf& b, size_t bytes)
 
 static void release(DevBuf& b)
 {
+    FDN_DEVICE_WIDE;
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr; b.cap = 0;
 }
@@ -248,6 +260,7 @@ static int ensure_pinned(fdn_ctx* h, size_t bytes)
 {
     if (h->pinned_cap >= bytes) return 0;
     FDN_HIP(hipStreamSynchronize(h->stream));
+    FDN_DEVICE_WIDE;
     if (h->pinned) { FDN_HIP(hipHostFree(h->pinned)); h->pinned = nullptr; h->pinned_cap = 0; }
     hipError_t e = hipHostMalloc(&h->pinned, bytes, hipHostMallocDefault);
     if (e != hipSuccess) { h->pinned = nullptr; return fail("hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
@@ -304,6 +317,7 @@ static void free_all(fdn_ctx* h)
     DevBuf* bufs[] = {&h->R, &h->M0, &h->M1, &h->flow, &h->stack, &h->sweep_out, &h->vol_a, &h->vol_b, &h->partials, &h->pair,
                       &h->vol_in, &h->vol_out, &h->Rpyr, &h->flow_pyr, &h->pyr_tmp, &h->area_tab, &h->fwd,
                       &h->sh_send, &h->sh_recv, &h->sh_stack, &h->sh_out[0], &h->sh_out[1], &h->sh_tmp};
+    FDN_DEVICE_WIDE;
     for (DevBuf* b : bufs) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     h->area_key = {0, 0, 0, 0};
 }
@@ -1378,6 +1392,7 @@ FDN_API int fdn_create(int device, fdn_handle* out)
     FDN_HIP(hipSetDevice(device));
     fdn_ctx* h = new fdn_ctx();
     h->device = device;
+    FDN_DEVICE_WIDE;
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
     h->stream = h->own_stream;
@@ -1400,6 +1415,7 @@ FDN_API int fdn_destroy(fdn_handle h)
     if (!h) return 0;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    FDN_DEVICE_WIDE;
     free_all(h);
     if (h->pinned) (void)hipHostFree(h->pinned);
     resolve_stamps(h);
@@ -1476,6 +1492,7 @@ FDN_API int fdn_malloc(fdn_handle h, size_t bytes, void** dptr)
 {
     FDN_ENTER(h);
     if (!dptr) return fail("dptr is NULL");
+    FDN_DEVICE_WIDE;
     FDN_HIP(hipMalloc(dptr, bytes ? bytes : 1));
     return 0;
 }
@@ -1483,6 +1500,7 @@ FDN_API int fdn_free(fdn_handle h, void* dptr)
 {
     FDN_ENTER(h);
     FDN_HIP(hipStreamSynchronize(h->stream));
+    FDN_DEVICE_WIDE;
     if (dptr) FDN_HIP(hipFree(dptr));
     return 0;
 }
