@@ -40,7 +40,6 @@
 // first B (no common slice, same code).
 #include "fdn_internal.h"
 #include "fdn_device.h"
-#include <stdlib.h>
 #include <algorithm>
 #include <utility>
 #include <vector>
@@ -365,9 +364,7 @@ static int launch_iter_t(const float* Rstack, const float* stack, const float* f
     const int BW = 64 - 2 * mh;
     const int nbands = (W + BW - 1) / BW;
     dim3 grid((unsigned)((long)nbands * pb.npairs));
-    // FDN_ITER_LDS_PAD: extra dynamic LDS per workgroup (an occupancy experiment knob: fewer workgroups per CU)
-    static const size_t lds_pad = getenv("FDN_ITER_LDS_PAD") ? (size_t)atol(getenv("FDN_ITER_LDS_PAD")) : 0;
-    const size_t lds = iter_lds_bytes(mh, acc != nullptr) * (TWO ? 2 : 1) + lds_pad;
+    const size_t lds = iter_lds_bytes(mh, acc != nullptr) * (TWO ? 2 : 1);
     const int fin = !flow_in ? 0 : fs.h > 0 ? 2 : 1;
     auto launch = [&](auto kern) -> int {
         if (lds > 48 * 1024) {      // a kernel must be told (per device and host thread) that it may take that much dynamic LDS:
