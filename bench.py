@@ -63,9 +63,22 @@ def parse():
     return ap.parse_args()
 
 
-def kernel_source_hash():
+# the sources a kernel is compiled from: a committed PMC pass of one kernel stays valid when another kernel's file changes
+KERNEL_SOURCES_OF = {"k_farneback_fused": ("fdn_fused.hip", "fdn_device.h"), "k_farneback_iter": ("fdn_iter.hip", "fdn_device.h"),
+                     "k_update_flow_scan": ("fdn_kernels.hip", "fdn_device.h")}
+
+
+def kernel_sources(kernel=None):
+    for name, files in KERNEL_SOURCES_OF.items():
+        if kernel and str(kernel).startswith(name):
+            return files
+    return KERNEL_SOURCES
+
+
+def kernel_source_hash(kernel=None):
+    """sha of the sources `kernel` is compiled from (all kernel sources when kernel is None)."""
     h = hashlib.sha256()
-    for fn in KERNEL_SOURCES:
+    for fn in kernel_sources(kernel):
         p = os.path.join(ROOT, "flowdenoising_amd", "csrc", fn)
         if os.path.exists(p):
             with open(p, "rb") as f:
@@ -140,7 +153,7 @@ def committed_profile(kernel, run_cfg):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True)
     if not files:
         return {"note": "no committed PMC pass"}
-    sha = kernel_source_hash()
+    sha = kernel_source_hash(kernel)
     why = []
     for fn in files:
         with open(fn) as f:

@@ -36,7 +36,8 @@ px = shape[0] * shape[1] * shape[2] * sum(0.25 ** k for k in range(levels + 1)) 
 nbytes = (2 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024
 res = {
     "kernel": kern,
-    "kernel_source_sha": bench.kernel_source_hash(),
+    "kernel_source_sha": bench.kernel_source_hash(kern),
+    "kernel_sources": list(bench.kernel_sources(kern)),
     "commit": commit,
     "command": "rocprofv3 --pmc <set> -- python bench.py" + bench_args
                + " --steps 1 --warmup 0 --no-cpu-baseline --no-timers --no-check "
