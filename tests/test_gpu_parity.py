@@ -219,6 +219,20 @@ def test_constant_volume(fdn):
     np.testing.assert_allclose(got, 37.5, rtol=1e-6)
 
 
+@pytest.mark.parametrize("shape,axis,border", [((1, 40, 44), 0, 0), ((1, 40, 44), 0, 1), ((2, 40, 44), 0, 0), ((9, 2, 70), 2, 0), ((9, 70, 2), 1, 1)])
+@pytest.mark.parametrize("l,w", [(0, 5), (1, 15)])
+def test_degenerate_extents(fdn, oracle, shape, axis, border, l, w):
+    """Edge cases of the sweep: an axis of length 1 or 2 under a kernel much longer than it (every neighbour of a target is a
+    mean-pad slice, or the target itself once wrapped), and images two pixels wide or high -- on both Farneback kernels.
+    Bit-equal to the oracle."""
+    vol = _vol(shape, seed=77)
+    k = fdn.get_gaussian_kernel(2.0)          # 17 taps
+    fn = [fdn.OF_filter_along_Z, fdn.OF_filter_along_Y, fdn.OF_filter_along_X][axis]
+    got = fn(vol, k, l, w, vol.mean(), border_mode=border)
+    want = oracle.filter_along_axis(vol, axis, k, l, w, vol.mean(), border_mode=border, nthreads=4)
+    assert np.array_equal(got, want), rel_err(got, want)
+
+
 def test_kernel_size_one_is_identity(fdn):
     vol = _vol((4, 34, 36))
     got = fdn.OF_filter(vol, [np.array([1.0]), None, None], 0, 5)
