@@ -284,6 +284,11 @@ def test_errors_are_loud(fdn):
     vol = _vol((4, 34, 36))
     with pytest.raises(FlowdnError):
         fdn.OF_filter(vol, [np.array([0.5, 0.5]), None, None], 0, 5)  # even kernel (seq:93 assert)
+    k = fdn.get_gaussian_kernel(1.0)
+    with pytest.raises(FlowdnError, match="at least 2x2"):
+        fdn.OF_filter_along_Z(_vol((4, 1, 36)), k, 0, 5, np.float32(0))     # optical flow between one-pixel-high images
+    with pytest.raises((FlowdnError, ValueError)):
+        fdn.OF_filter_along_Z(np.zeros((0, 34, 36), np.float32), k, 0, 5, np.float32(0))     # an empty volume
 
 
 def _random_cases(n, seed):
