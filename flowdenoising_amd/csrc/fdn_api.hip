@@ -160,6 +160,11 @@ struct DevBuf {
 };
 
 struct fdn_ctx {
+    // Every entry point that takes a handle holds this for the whole call (FDN_ENTER): par calls its pair operators from P
+    // pool threads at once (src/flowdenoising.py:187-193, 299-327) and all of them may share one handle -- its stream, its
+    // pinned staging buffer and its device scratch are then used by one call at a time.  Recursive: some entry points are
+    // written in terms of others (fdn_farneback -> fdn_farneback_strided, the sharded mean -> fdn_np_chunk_sums_dev).
+    std::recursive_mutex mu;
     bool reserve_only = false;   // fdn_reserve_3d: size and allocate every buffer of a call, launch nothing
     size_t reserve_extern = 0;   // ... leaving this much free: the caller's own input / output volumes, not allocated yet
     int device = 0;
@@ -1413,21 +1418,25 @@ FDN_API int fdn_create(int device, fdn_handle* out)
 FDN_API int fdn_destroy(fdn_handle h)
 {
     if (!h) return 0;
-    (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->stream);
-    FDN_DEVICE_WIDE;
-    free_all(h);
-    if (h->pinned) (void)hipHostFree(h->pinned);
-    resolve_stamps(h);
-    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
-    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
-    if (h->trace_fd >= 0) close(h->trace_fd);
+    {   // a call still running on another thread finishes first (the caller must not START one after this: the handle is gone)
+        std::lock_guard<std::recursive_mutex> enter_guard_(h->mu);
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+        FDN_DEVICE_WIDE;
+        free_all(h);
+        if (h->pinned) (void)hipHostFree(h->pinned);
+        resolve_stamps(h);
+        for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+        if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+        if (h->trace_fd >= 0) close(h->trace_fd);
+    }
     delete h;
     return 0;
 }
 
-#define FDN_ENTER(h)                              \
-    if (!(h)) return fail("handle is NULL");      \
+#define FDN_ENTER(h)                                                  \
+    if (!(h)) return fail("handle is NULL");                          \
+    std::lock_guard<std::recursive_mutex> enter_guard_((h)->mu);      \
     FDN_HIP(hipSetDevice((h)->device))
 
 FDN_API int fdn_set_stream(fdn_handle h, void* s)

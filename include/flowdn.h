@@ -16,7 +16,14 @@
  *     torch tensor's data_ptr()); the others take HOST pointers and stage through
  *     library-owned device memory.  All work is enqueued on the handle's HIP stream;
  *     host-pointer calls return after the result has been copied back.
- *   - one handle per GPU per host thread; a handle is not re-entrant.
+ *   - thread safety: every entry point that takes a handle holds the handle's own lock for the whole call, so ONE
+ *     handle may be shared by any number of host threads -- par calls its pair operators from P pool threads at once
+ *     (par:187-193, 299-327); their calls then run one after the other on the handle's stream, each with the handle's
+ *     staging buffers to itself.  Threads that want their calls to OVERLAP use a handle each (handles are independent;
+ *     device-wide runtime operations -- allocation, stream and event creation -- are serialised across the handles of a
+ *     process by the library).  fdn_destroy waits for a call in flight; no call may START on a handle once fdn_destroy
+ *     has been called for it.  fdn_last_error() is per thread.  The `fdn_comm` callbacks of fdn_filter_3d_sharded are
+ *     called with the handle's lock held: they must not call back into the same handle from another thread and wait.
  */
 #ifndef FLOWDN_H
 #define FLOWDN_H

@@ -13,18 +13,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_subprocess: a GPU test that starts other GPU processes (runs after the in-process GPU tests)")
 
 
 def _starts_gpu_processes(item):
-    """A GPU test that runs other GPU processes (the CLI, bench.py, rank processes of the transports)."""
-    if item.get_closest_marker("gpu") is None:
-        return False
-    try:
-        import inspect
-        src = inspect.getsource(item.function)
-    except (OSError, TypeError, AttributeError):
-        return False
-    return "subprocess." in src or "launch.spawn" in src or "run_in_fresh_process" in src
+    """A GPU test that runs other GPU processes (the CLI, bench.py, rank processes of the transports, run_in_fresh_process):
+    marked `@pytest.mark.gpu_subprocess` by hand (tests/test_abi_and_host.py checks that no test that starts one is unmarked)."""
+    return item.get_closest_marker("gpu") is not None and item.get_closest_marker("gpu_subprocess") is not None
 
 
 def pytest_collection_modifyitems(config, items):

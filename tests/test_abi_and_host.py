@@ -379,3 +379,27 @@ def test_mapped_mrc_writer_writes_the_file_write_mrc_writes(tmp_path):
         w.close()                                   # a second close is harmless
         assert open(tmp_path / name, "rb").read() == want
         assert getattr(h, "live", 0) == 0
+
+
+def test_gpu_tests_that_start_processes_are_marked():
+    """conftest orders `gpu_subprocess` tests after the in-process GPU tests (its docstring says why).  The marker is put
+    on by hand; this is the lint that a GPU test which starts another GPU process has not been left unmarked."""
+    import ast
+    import glob
+    missing = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "tests", "test_*.py"))):
+        src = open(path).read()
+        lines = src.splitlines()
+        module_gpu = re.search(r"^pytestmark = pytest\.mark\.gpu\b", src, re.M) is not None
+        for node in ast.parse(src).body:
+            if not (isinstance(node, ast.FunctionDef) and node.name.startswith("test_")):
+                continue
+            first = node.decorator_list[0].lineno - 1 if node.decorator_list else node.lineno - 1
+            decorators = "\n".join(lines[first:node.lineno - 1])
+            body = "\n".join(lines[node.lineno - 1:node.end_lineno])
+            if not (module_gpu or "mark.gpu" in decorators):
+                continue
+            starts = "subprocess." in body or "launch.spawn" in body or "run_in_fresh_process" in body
+            if starts and "mark.gpu_subprocess" not in decorators:
+                missing.append(f"{os.path.basename(path)}::{node.name}")
+    assert not missing, f"GPU tests that start processes without @pytest.mark.gpu_subprocess: {missing}"

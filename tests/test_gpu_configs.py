@@ -28,6 +28,7 @@ def _uint16_range(vol):
 
 
 # ---- configs[0]: 128 x 128 x 64 float32 MRC, sigma = 2, default Farneback parameters, through the CLI ----------
+@pytest.mark.gpu_subprocess
 def test_config0_full_size_mrc_cli(fdn, oracle, tmp_path):
     from flowdenoising_amd import io as fio
     from flowdenoising_amd.synth import make_volume
@@ -135,6 +136,7 @@ def test_config4_full_size_images_spot_parity(fdn, oracle, axis, shape, sigma, t
         assert rel_err(np.take(got, [t], axis=axis), np.take(want, [t - lo], axis=axis)) < TIGHT_TOL, (axis, t)
 
 
+@pytest.mark.gpu_subprocess
 def test_config4_uint16_tiff_cli_end_to_end(fdn, oracle, tmp_path):
     """uint16 multi-page TIFF -> flowdenoising.py -s 2 2 4 -l 3 -w 15 -> TIFF, 2048 x 2048 pages, thin in Z:
     float32 conversion on input (seq:517), uint8/uint16 down-cast on output (seq:566-571: astype truncates)."""

@@ -20,6 +20,7 @@ def _vol(shape, seed=7):
     return make_volume(shape, seed=seed, amplitude=100.0)
 
 
+@pytest.mark.gpu_subprocess
 def test_cli_mrc_end_to_end_config0(fdn, oracle, tmp_path):
     """BASELINE configs[0] in miniature: float32 MRC in, float32 MRC out, defaults of the oracle script."""
     from flowdenoising_amd import io as fio
@@ -34,6 +35,7 @@ def test_cli_mrc_end_to_end_config0(fdn, oracle, tmp_path):
     assert got.dtype == np.float32 and rel_err(got, want) < TIGHT_TOL
 
 
+@pytest.mark.gpu_subprocess
 def test_cli_tiff_uint16_no_of_and_par_compat(fdn, oracle, tmp_path):
     from flowdenoising_amd import io as fio
     vol = (np.clip(_vol((6, 34, 36), seed=4), 0, None) * 4).astype(np.uint16)
@@ -53,6 +55,7 @@ def test_cli_tiff_uint16_no_of_and_par_compat(fdn, oracle, tmp_path):
     assert got.dtype == np.float32 and rel_err(got, want) < TIGHT_TOL                 # par:548, par:312
 
 
+@pytest.mark.gpu_subprocess
 def test_cli_gpus_2_shards_reads_and_gathers(fdn, tmp_path):
     """flowdenoising.py --gpus 2: re-launches itself under torch.distributed.run, every rank reads its own Z-slab of
     the file, the mean is assembled from chunk sums, rank 0 gathers and writes -- the output equals the single-GPU
@@ -67,6 +70,7 @@ def test_cli_gpus_2_shards_reads_and_gathers(fdn, tmp_path):
     assert np.array_equal(fio.read_mrc(str(tmp_path / "two.mrc")), fio.read_mrc(str(tmp_path / "one.mrc")))
 
 
+@pytest.mark.gpu_subprocess
 def test_bench_line_contract(fdn):
     """bench.py on a small volume: ONE JSON line with the contract's keys, a roofline fraction that is a fraction, the
     post-run oracle check green and a CPU baseline beside it."""
@@ -99,6 +103,59 @@ def test_flowdenoising_class_mirrors_par(fdn, oracle):
     assert rel_err(fd.filtered_vol, want) < TIGHT_TOL and np.array_equal(fd.vol, fd.filtered_vol)
 
 
+@pytest.mark.gpu_subprocess
+@pytest.mark.parametrize("dtype", [np.float32, np.int16])
+def test_pair_operators_under_pars_thread_pool(fdn, oracle, tmp_path, dtype):
+    """The seam par injects into (`FlowDenoising(P, vol, l, w, get_flow, warp_slice)`, par:506) as par itself uses it:
+    P = 8 pool threads call get_flow / warp_slice at once on views of one shared volume (par:187-193, 299-327;
+    tests/_par_pool.py restates the scheduler and the slice loops).  All of them go through the ONE process-wide handle
+    behind `flowdenoising_amd.get_flow_with_prev_flow` / `warp_slice`; the C ABI serialises them (a lock per handle), so
+    the eight-thread result must be the single-thread one bit for bit -- and both the oracle's for the same loops.
+    Axis lengths 17 / 66 / 83 leave a remainder round on every pass.  Runs in a process of its own (conftest)."""
+    from conftest import run_in_fresh_process
+    import _par_pool
+    if dtype == np.float32:
+        vol = _vol((17, 66, 83), seed=21)
+    else:
+        v = _vol((17, 66, 83), seed=22)
+        vol = (np.round((v - v.min()) / (v.max() - v.min()) * 4095) - 1500).astype(np.int16)
+    ks = [fdn.get_gaussian_kernel(1.0), fdn.get_gaussian_kernel(0.5), fdn.get_gaussian_kernel(1.0)]
+    code = (
+        "import flowdenoising_amd as fdn, _par_pool, threading\n"
+        "ks = [k0, k1, k2]\n"
+        "seen = set()\n"
+        "def gf(reference, target, l, w, prev_flow):\n"
+        "    seen.add(threading.get_ident())\n"
+        "    return fdn.get_flow_with_prev_flow(reference, target, l, w, prev_flow)\n"
+        "out['pool'] = _par_pool.par_sweep(gf, fdn.warp_slice, vol, ks, 0, 5, 8)\n"
+        "out['threads'] = np.array([len(seen)])\n"
+        "out['single'] = _par_pool.par_sweep(fdn.get_flow_with_prev_flow, fdn.warp_slice, vol, ks, 0, 5, 1)\n"
+        "v = vol.copy()\n"
+        "fdn.FlowDenoising(8, v, 0, 5, fdn.get_flow_with_prev_flow, fdn.warp_slice).filter(ks)\n"
+        "out['batched'] = v\n")
+    got, _ = run_in_fresh_process(code, {"vol": vol, "k0": ks[0], "k1": ks[1], "k2": ks[2]}, tmp_path)
+    assert got["threads"][0] >= 4, "the pool's threads did not all reach the library"
+    assert got["pool"].dtype == vol.dtype and np.array_equal(got["pool"], got["single"])
+
+    def o_flow(reference, target, l, w, prev_flow):
+        return oracle.get_flow(np.asarray(reference, np.float32), np.asarray(target, np.float32), l, w, prev_flow)
+
+    def o_warp(reference, flow):
+        H, W = flow.shape[:2]
+        m = np.empty((H, W, 2), np.float32)
+        m[..., 0] = (flow[..., 0].astype(np.float64) + np.arange(W)[None, :]).astype(np.float32)     # seq:53-55
+        m[..., 1] = (flow[..., 1].astype(np.float64) + np.arange(H)[:, None]).astype(np.float32)
+        return oracle.remap_any(np.ascontiguousarray(reference), m)
+
+    want = _par_pool.par_sweep(o_flow, o_warp, vol, ks, 0, 5, 1)
+    if dtype == np.float32:
+        assert rel_err(got["pool"], want) < TIGHT_TOL
+    else:
+        assert np.array_equal(got["pool"], want)
+    # and the batched sweep the package runs for the same class (one launch per chain step of every target)
+    assert rel_err(got["batched"], want) < TIGHT_TOL if dtype == np.float32 else np.array_equal(got["batched"], want)
+
+
 def test_slab_engine_on_hip_backend_world1(fdn, oracle):
     torch = pytest.importorskip("torch")
     from flowdenoising_amd import _lib
@@ -120,6 +177,7 @@ def test_slab_engine_on_hip_backend_world1(fdn, oracle):
     assert rel_err(out, want) < TIGHT_TOL
 
 
+@pytest.mark.gpu_subprocess
 @pytest.mark.parametrize("world,shape,sig,border,l", [(2, (12, 70, 150), "1.0,0.5,1.0", 0, 0), (3, (13, 64, 128), "1.0,-,0.5", 1, 1),
                                                       (4, (10, 66, 140), "1.5,0.5,1.0", 0, 0)])    # 4 ranks + this process: under the box's limit of 6
 def test_slab_engine_on_hip_backend_multi_rank(fdn, tmp_path, world, shape, sig, border, l):
@@ -156,6 +214,7 @@ def test_slab_engine_on_hip_backend_multi_rank(fdn, tmp_path, world, shape, sig,
     assert np.array_equal(got_c, want)
 
 
+@pytest.mark.gpu_subprocess
 def test_rccl_world_size_1_carries_the_slab_engine(fdn, tmp_path):
     """One real RCCL communicator on the one GPU every box has: a world-size-1 `nccl` process group carries the slab
     engine in loopback mode -- the blocks of every exchange travel as send-to-self messages inside the batched group
@@ -182,6 +241,7 @@ def test_rccl_world_size_1_carries_the_slab_engine(fdn, tmp_path):
     assert np.load(f"{tmp_path}/o.mean.npy") == vol.mean()
 
 
+@pytest.mark.gpu_subprocess
 def test_bench_gpus_2_from_a_bare_shell(fdn):
     """`python3 bench.py --gpus 2 ...` the way the driver calls it (no torch.distributed.run around it): bench.py starts
     its ranks as a child process, relays rank 0's line and exits with the child's code.  On a one-GPU box the two ranks
@@ -203,6 +263,7 @@ def test_bench_gpus_2_from_a_bare_shell(fdn):
     assert c["ok"] and c["sharded_output_equals_single_gpu_rerun"] and c["bit_equal"] and len(c["slices"]) == 3
 
 
+@pytest.mark.gpu_subprocess
 def test_bench_gpus_2_under_torch_distributed_run(fdn):
     """The round driver's launch for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
     127.0.0.1 --master-port P bench.py --gpus N ...`.  torch.distributed.run only starts the ranks: they find each other through
@@ -229,6 +290,7 @@ def test_bench_gpus_2_under_torch_distributed_run(fdn):
     assert not glob.glob(os.path.join("/dev/shm", f"fdn_rdv_{os.getuid()}_{port}_*")) and not glob.glob(os.path.join(tempfile.gettempdir(), f"fdn_rdv_{os.getuid()}_{port}_*"))
 
 
+@pytest.mark.gpu_subprocess
 def test_bench_gpus_2_python_engine(fdn):
     """--engine python: the torch.distributed slab engine (gloo rehearsal on a one-GPU box, RCCL with two GPUs), started by
     bench.py itself under torch.distributed.run."""
@@ -385,6 +447,7 @@ def test_strict_order_refuses_rows_it_cannot_hold(fdn):
         h.set_option("strict_order", 0)
 
 
+@pytest.mark.gpu_subprocess
 @pytest.mark.parametrize("env", [{}, {"FDN_FUSED_OCC": "3"}, {"FDN_FUSED_OCC": "4"}, {"FDN_FUSED_OCC": "5"}, {"FDN_FUSED_OCC": "8"}, {"FDN_FORCE_STAGED": "1"}, {"FDN_PATH": "2"}])
 def test_kernel_variants_agree_bit_for_bit(fdn, oracle, tmp_path, env):
     """Every implementation of the chain step (the fused stage-pipelined kernel in its builds for 3, 4
@@ -613,6 +676,7 @@ def test_non_finite_voxels_do_not_derail_the_kernels(fdn):
         assert not np.isfinite(out[5, 20:, 28:33]).all()
 
 
+@pytest.mark.gpu_subprocess
 @pytest.mark.parametrize("l,border,chunk", [(0, 0, 3), (1, 0, 4), (0, 1, 5), (0, 0, None)])
 def test_streamed_filter_equals_resident_filter(fdn, tmp_path, l, border, chunk):
     """Out-of-core mode (volume on the host, chunks of a pass's slices on the GPU): bit-identical to the
@@ -631,6 +695,7 @@ def test_streamed_filter_equals_resident_filter(fdn, tmp_path, l, border, chunk)
     assert np.array_equal(got["no_of"], fdn.no_OF_filter(vol, ks))
 
 
+@pytest.mark.gpu_subprocess
 def test_strict_order_mode_reproduces_opencvs_horizontal_running_sum(oracle, tmp_path):
     """The fast kernels sum the box filter's horizontal window directly; OpenCV runs a serial f64 chain along
     the row.  In one of 7 080 random configurations that 1e-16 difference flipped an f32 rounding (5.8e-5 in
@@ -655,6 +720,7 @@ def test_strict_order_mode_reproduces_opencvs_horizontal_running_sum(oracle, tmp
     assert not np.array_equal(outs["0"], want) and rel_err(outs["0"], want) < 1e-4
 
 
+@pytest.mark.gpu_subprocess
 @pytest.mark.parametrize("shape,l,w", [((5, 24, 2048), 0, 5), ((4, 70, 2048), 3, 15), ((3, 20, 3000), 0, 7), ((4, 9, 63), 0, 15), ((3, 5, 3), 0, 5)])
 def test_strict_order_on_rows_of_2048_pixels_and_more(fdn, oracle, tmp_path, shape, l, w):
     """(The last two shapes: rows narrower than a segment's minimum are one segment.)
@@ -709,6 +775,7 @@ def test_volume_statistics_slice_form_and_nan(fdn):
 
 
 # ---- the native transports (libflowdn_rccl.so): no torch in any of these processes ---------------------------------------
+@pytest.mark.gpu_subprocess
 @pytest.mark.parametrize("with_torch", [False, True])
 def test_native_rccl_world_size_1_loopback(fdn, tmp_path, with_torch):
     """One real RCCL communicator made by libflowdn_rccl.so itself (ncclGetUniqueId / ncclCommInitRank, no torch in the
@@ -733,6 +800,7 @@ def test_native_rccl_world_size_1_loopback(fdn, tmp_path, with_torch):
     assert np.array_equal(np.load(f"{tmp_path}/o.0.npy"), fdn.OF_filter(vol, ks, 0, 5))
 
 
+@pytest.mark.gpu_subprocess
 @pytest.mark.parametrize("world,shape,sig,border,l", [(2, (12, 70, 150), "1.0,0.5,1.0", 0, 0), (3, (13, 64, 128), "1.0,-,0.5", 1, 1),
                                                       (4, (10, 66, 140), "1.5,0.5,1.0", 0, 0),
                                                       # (four ranks + this process stay under the box's limit of six GPU processes) slabs of 2-3
@@ -757,6 +825,7 @@ def test_native_transport_multi_rank(fdn, tmp_path, world, shape, sig, border, l
     assert np.array_equal(got, fdn.OF_filter(vol, ks, l, 5, border_mode=border))
 
 
+@pytest.mark.gpu_subprocess
 @pytest.mark.parametrize("suffix,dtype,compat", [("mrc", np.float32, "seq"), ("mrc", np.int16, "seq"), ("tif", np.uint16, "seq"), ("tif", np.float32, "par")])
 def test_cli_gpus_2_is_torch_free_and_writes_the_single_gpu_file(fdn, tmp_path, suffix, dtype, compat):
     """`python flowdenoising.py --gpus 2`: two rank processes (subprocess.Popen, no torch.distributed.run), each reads its
@@ -803,6 +872,7 @@ def _write_mrc_any(path, vol):
 
 
 # ---- the C engine at world 7 and 8: rank THREADS in this process (the boxes allow six GPU processes) -----------------------
+@pytest.mark.gpu_subprocess
 @pytest.mark.parametrize("world,shape,sig,border,l,w,dtype", [
     (8, (16, 66, 140), "1.0,0.5,1.0", 0, 0, 5, np.float32),      # two slices per rank, mean-padded
     (8, (19, 70, 64), "1.5,1.5,-", 1, 0, 5, np.float32),         # wrap-around; K//2 = 6 exceeds every slab (2-3 slices): halos from three ranks away
@@ -845,6 +915,7 @@ def _bench_line(stdout):
     return json.loads(lines[0])
 
 
+@pytest.mark.gpu_subprocess
 def test_bench_line_proves_its_ranks_and_devices(fdn):
     """The N > 1 line says who was there as the communicator reports it (`n_ranks_seen` = ncclCommCount over RCCL, the
     distinct ranks heard from over shared memory) and which GPU every rank sat on (`devices`: all-gathered PCI bus ids):
@@ -861,6 +932,7 @@ def test_bench_line_proves_its_ranks_and_devices(fdn):
     assert "transport_fallback" not in d and d["checked"]["ok"]
 
 
+@pytest.mark.gpu_subprocess
 @pytest.mark.parametrize("how", ["bare", "torchrun"])
 def test_bench_falls_back_to_fresh_ranks_when_the_native_job_fails(fdn, how):
     """A native start-up failure must not leave an `rc != 0` record without a number.  From a bare shell the parent -- which
@@ -893,6 +965,7 @@ def test_bench_falls_back_to_fresh_ranks_when_the_native_job_fails(fdn, how):
     assert r.returncode != 0 and "injected failure" in r.stderr
 
 
+@pytest.mark.gpu_subprocess
 def test_cli_gpus_refuses_more_ranks_than_slices_and_a_failing_rank_stops_the_job(fdn, tmp_path):
     """`--gpus N` with an axis shorter than N is refused by the parent, before any rank starts; a rank that fails (rank 0
     cannot create the output file) tells the others, which leave their barrier at once instead of waiting for the timeout."""

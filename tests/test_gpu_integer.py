@@ -63,6 +63,7 @@ def test_seq_semantics_on_every_path_and_no_of(fdn, oracle):
     assert not np.array_equal(one, fdn.OF_filter_along_Z(f32, ks[0], 0, 5, np.float32(m64)))
 
 
+@pytest.mark.gpu_subprocess
 def test_seq_semantics_chunked_and_streamed(fdn, oracle, tmp_path):
     """The pad slices of every chunk are found again when a workspace limit cuts the passes, and in the out-of-core mode
     (whose worker threads run in a fresh process: conftest.run_in_fresh_process)."""
@@ -150,6 +151,7 @@ def test_par_semantics_no_of_and_unsupported_types(fdn, oracle):
         fdn.OF_filter(vol.astype(np.int32), ks, 0, 5)
 
 
+@pytest.mark.gpu_subprocess
 def test_cli_on_an_int16_mrc(fdn, oracle, tmp_path):
     """flowdenoising.py on a mode-1 MRC: seq semantics by default, par's with --compat par; float32 MRC out either way."""
     from flowdenoising_amd import io as fio
