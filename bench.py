@@ -54,8 +54,6 @@ def parse():
     ap.add_argument("--engine", choices=("native", "python"), default="native", help="N > 1: fdn_filter_3d_sharded on the native transport "
                     "(libflowdn_rccl.so: RCCL, or shared memory when ranks share a GPU), or the torch.distributed slab engine above the C ABI (distributed.py)")
     ap.add_argument("--path", type=int, default=0, help="fdn_set_option path: 0 auto, 1 staged, 2 per-iteration kernels")
-    ap.add_argument("--two-sided", type=int, default=0, help="fdn_set_option two_sided: both sides of a chain step in one launch, mirror pairs in one workgroup "
-                    "(bit 0: one-iteration kernel, bit 1: 3-iteration kernel); 0 = one launch per side, the product default -- for A/B runs")
     ap.add_argument("--cpu-targets", type=int, default=0, help="target slices of the CPU sample (0 = four per core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check and the sweep-kernel line")
@@ -91,19 +89,15 @@ def kernel_source_hash(kernel=None):
 #       flow out 8 on the chain steps that have them ((K-3)/(K-1) of the launches each)
 #   iter (one Farneback iteration per launch): R0 20 + R1 20 + flow in 8 + flow out 8 = 56; the last of three also warps: +12
 #   update_flow (staged FarnebackUpdateFlow_Blur): M 20 + flow 8, plus on the refreshing launches R0 20 + R1 20 + flow 8 + M 20
-#   two-sided launches (--two-sided, an A/B option): the mirror pairs of a workgroup fetch each expansion once for both: 20 per
-#       pair instead of 40; the forward pair stores a 4-byte value instead of reading and writing the accumulator: 6 instead of 8
-def compulsory_bytes_per_px(name, K, two=False):
+def compulsory_bytes_per_px(name, K):
     if name == "fused":
-        return (30.0 if two else 52.0) + 16.0 * (K - 3) / (K - 1)
+        return 52.0 + 16.0 * (K - 3) / (K - 1)
     if name == "iter":
-        if two:
-            return 36.0 + 10.0 / 3 - 8.0 / 3 * 2.0 / (K - 1)
         return 56.0 + 12.0 / 3 - 8.0 / 3 * 2.0 / (K - 1)     # the first launch of each side's chain has no flow to read
     return (3 * 28 + 2 * 68) / 3.0
 
 
-def roofline(timers, nvox, K, levels, run_cfg, two_sided=0):
+def roofline(timers, nvox, K, levels, run_cfg):
     """The dominant kernel against the HBM peak, priced on the bytes it has to move."""
     names = {"fused": "k_farneback_fused", "iter": "k_farneback_iter", "update_flow": "k_update_flow_scan"}
     best = None
@@ -115,10 +109,9 @@ def roofline(timers, nvox, K, levels, run_cfg, two_sided=0):
         return None
     name, ms, cnt = best
     # with a pyramid a chain step is one launch (three for `iter`) per level; level k has 4^-k of the pixels
-    two = (name == "iter" and two_sided & 1) or (name == "fused" and two_sided & 2)
-    px_per_launch = nvox * sum(0.25 ** k for k in range(levels + 1)) / (levels + 1) * (2 if two else 1)     # pixels x pairs of a launch
+    px_per_launch = nvox * sum(0.25 ** k for k in range(levels + 1)) / (levels + 1)     # pixels x pairs of a launch
     avg_s = ms / cnt * 1e-3
-    bpp = compulsory_bytes_per_px(name, K, bool(two))
+    bpp = compulsory_bytes_per_px(name, K)
     achieved = bpp * px_per_launch / avg_s / 1e9
     unfused = {"fused": 300.0, "iter": 100.0, "update_flow": (3 * 28 + 2 * 68) / 3.0}[name]
     r = {"bound": "hbm", "kernel": names[name], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -131,9 +124,7 @@ def roofline(timers, nvox, K, levels, run_cfg, two_sided=0):
                                  "note": "SURVEY 8(d) stage list with every named intermediate through HBM; exceeds the "
                                          "peak exactly when fusion removed that traffic -- not an HBM fraction"},
          "traffic": None}
-    if two:
-        r["two_sided"] = "both sides of a chain step in this launch (mirror pairs in one workgroup): an A/B option, not the default"
-    t = committed_profile(names[name], run_cfg) if not two else {"note": "committed PMC passes are of the default (one launch per side)"}
+    t = committed_profile(names[name], run_cfg)
     r["traffic_source"] = t["note"]
     if t.get("bytes_per_px") is not None:
         traffic = t["bytes_per_px"] * px_per_launch
@@ -505,7 +496,6 @@ def run(a, job, fallback):
     #  synchronisation on either side of the timed region)
     if a.path:
         h.set_option("path", a.path)
-    h.set_option("two_sided", a.two_sided)
 
     eng = None
     out_slab = None
@@ -639,7 +629,7 @@ def run(a, job, fallback):
                              "note": "SURVEY 8(d) bytes of the unfused stage list / wall time; a ratio above 1 = traffic that fusion removed"}
         if timers:
             run_cfg = {"shape": list(shape), "winsize": a.winsize, "levels": a.levels, "sigma": a.sigma if not a.sigmas else a.sigmas, "axes": a.axes}
-            res["roofline"] = roofline(timers, nvox // world, kernel.size, a.levels, run_cfg, a.two_sided)
+            res["roofline"] = roofline(timers, nvox // world, kernel.size, a.levels, run_cfg)
             res["kernel_ms_per_step"] = {k: round(v[0] / a.steps, 2) for k, v in timers.items() if v[1]}
         if phases:
             res["phase_ms_per_step_per_rank"] = phases

@@ -354,7 +354,7 @@ class Handle:
         return f.value, t.value
 
     def set_option(self, name, value):
-        """fdn_set_option: "strict_order", "path", "fused_occ", "lds_pad", "shard_loopback", "two_sided" (see include/flowdn.h)."""
+        """fdn_set_option: "strict_order", "path", "fused_occ", "lds_pad", "shard_loopback" (see include/flowdn.h)."""
         check(self._lib.fdn_set_option(self._h, ctypes.c_char_p(name.encode()), ctypes.c_long(int(value))))
 
     def malloc(self, nbytes):

@@ -176,7 +176,6 @@ struct fdn_ctx {
     void* pinned = nullptr;          // host staging of the pair-level entry points (hipHostMalloc)
     size_t pinned_cap = 0;
     DevBuf Rpyr, flow_pyr, pyr_tmp, area_tab;   // pyramid levels >= 1
-    DevBuf fwd;                                 // two-sided chain steps: the forward side's warped values, [K/2][targets][H*W]
     DevBuf sh_send, sh_recv, sh_stack, sh_out[2], sh_tmp;   // fdn_filter_3d_sharded: staging, stack and pass outputs
     struct AreaKey { int sh, sw, dh, dw; } area_key = {0, 0, 0, 0};
     struct AreaPtrs { const int *x_si, *x_start, *y_si, *y_start; const float *x_alpha, *y_alpha; } area = {};
@@ -310,7 +309,7 @@ static int gather_host_depth(float* dst, const void* src, int depth, ptrdiff_t r
 static size_t owned_bytes(const fdn_ctx* h)
 {
     const DevBuf* bufs[] = {&h->R, &h->M0, &h->M1, &h->flow, &h->stack, &h->sweep_out, &h->vol_a, &h->vol_b, &h->partials, &h->pair,
-                            &h->vol_in, &h->vol_out, &h->Rpyr, &h->flow_pyr, &h->pyr_tmp, &h->area_tab, &h->fwd,
+                            &h->vol_in, &h->vol_out, &h->Rpyr, &h->flow_pyr, &h->pyr_tmp, &h->area_tab,
                             &h->sh_send, &h->sh_recv, &h->sh_stack, &h->sh_out[0], &h->sh_out[1], &h->sh_tmp};
     size_t n = 0;
     for (const DevBuf* b : bufs) n += b->cap;
@@ -320,7 +319,7 @@ static size_t owned_bytes(const fdn_ctx* h)
 static void free_all(fdn_ctx* h)
 {
     DevBuf* bufs[] = {&h->R, &h->M0, &h->M1, &h->flow, &h->stack, &h->sweep_out, &h->vol_a, &h->vol_b, &h->partials, &h->pair,
-                      &h->vol_in, &h->vol_out, &h->Rpyr, &h->flow_pyr, &h->pyr_tmp, &h->area_tab, &h->fwd,
+                      &h->vol_in, &h->vol_out, &h->Rpyr, &h->flow_pyr, &h->pyr_tmp, &h->area_tab,
                       &h->sh_send, &h->sh_recv, &h->sh_stack, &h->sh_out[0], &h->sh_out[1], &h->sh_tmp};
     FDN_DEVICE_WIDE;
     for (DevBuf* b : bufs) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
@@ -613,20 +612,9 @@ static int sweep_path(const fdn_ctx* h, const fdn_sweep_params* p, const std::ve
 }
 // bytes of flows (and matrices) per pixel of a target slice on that path: fused / iter: two buffers (16 B), with a pyramid
 // two more per coarser level (22); per-stage: one flow per step of a side (8 r B) + two M sets (40 B)
-// two-sided chain steps (`two`): both sides' flows at once (32, 44 with a pyramid) + the forward side's r warped values
-// (4 r; 8 r as doubles in warp mode 1)
-static size_t sweep_flow_px(int path, int r, bool pyramid, bool two = false, bool f64 = false)
+static size_t sweep_flow_px(int path, int r, bool pyramid)
 {
-    if (two) return (pyramid ? 44 : 32) + (size_t)(f64 ? 8 : 4) * std::max(r, 1);
     return path < 2 ? (pyramid ? 22 : 16) : (size_t)8 * std::max(r, 1) + 40 + (pyramid ? 4 : 0);
-}
-// which sweeps run two-sided: the one-iteration kernel's (fdn_iter.hip, TWO); needs a real chain (r >= 1)
-static bool sweep_two_sided(const fdn_ctx* h, const fdn_sweep_params* p, int path, int r)
-{
-    if (r < 1 || r > FoldWeights::MAX) return false;
-    if (path == 1) return (h->tn.two_sided & 1) != 0;
-    if (path == 0) return (h->tn.two_sided & 2) != 0 && fused_two_supported(p->winsize);
-    return false;
 }
 
 // One chain step on the one-iteration kernels (fdn_iter.hip): calc()'s levels, coarsest first, `iters` launches each;
@@ -663,74 +651,6 @@ static int chain_step_iter(fdn_ctx* h, const std::vector<PyrLevel>& lv, const fl
         ch = lv[k].h; cw = lv[k].w;   // the next (finer) level upsamples this one's result
     }
     *result = const_cast<float*>(fin);
-    return 0;
-}
-
-// The same for both sides of chain step pb.d = a at once (launch_farneback_iter_two): every buffer holds [F pairs][B pairs];
-// `prev` / bufs as above with 2 n images each; fwd_values: where the forward side's warped values of this step go.
-static int chain_step_iter_two(fdn_ctx* h, const std::vector<PyrLevel>& lv, const float* R0, const float* stack, const float* prev,
-                               float* const bufs[2], float* acc, void* fwd_values, PairBatch pb, int H, int W, int winsize, int iters,
-                               double weight_back, bool keep, float** result, const WarpMode& wm)
-{
-    const int L = (int)lv.size() - 1;
-    float* fp = (float*)h->flow_pyr.p;
-    const int n2 = 2 * pb.npairs;
-    const float* fin = prev;
-    int ch = 0, cw = 0;
-    if (L > 0 && prev) {
-        float* a = fp + lv[L].f_off;
-        ScopedTimer t(h, FDN_TIMER_PERMUTE);
-        if (resize_dev(h, prev, H, W, a, lv[L].h, lv[L].w, 2, n2, 3, true, lv[L].scale)) return -1;
-        fin = a;
-    }
-    for (int k = L; k >= 0; k--) {
-        float* A = k ? fp + lv[k].f_off : bufs[0];
-        float* B = k ? A + (size_t)n2 * lv[k].h * lv[k].w * 2 : bufs[1];
-        const float* Rk = k ? (const float*)h->Rpyr.p + lv[k].r_off : R0;
-        for (int it = 0; it < iters; it++) {
-            const bool last = k == 0 && it == iters - 1;
-            float* fout = fin == A ? B : A;
-            ScopedTimer t(h, FDN_TIMER_ITER);
-            if (launch_farneback_iter_two(Rk, stack, fin, last && !keep ? nullptr : fout, last ? acc : nullptr, last ? fwd_values : nullptr, pb,
-                                          lv[k].h, lv[k].w, winsize, weight_back, h->stream, ch, cw, wm))
-                return fail("k_farneback_iter (two-sided) could not be launched (winsize %d needs %zu bytes of LDS)", winsize, 2 * iter_lds_bytes(winsize / 2, true));
-            fin = fout; ch = cw = 0;
-        }
-        ch = lv[k].h; cw = lv[k].w;
-    }
-    *result = const_cast<float*>(fin);
-    return 0;
-}
-
-// One two-sided chain step on the 3-iteration kernel (launch_farneback_fused_two): calc()'s levels, coarsest first, one launch
-// each; flows are [F pairs][B pairs].  prev: the previous step's flows (2 n images) or nullptr; out0: where this step's go (or nullptr).
-static int chain_step_fused_two(fdn_ctx* h, const std::vector<PyrLevel>& lv, const float* R0, const float* stack, const float* prev,
-                                float* out0, float* acc, void* fwd_values, PairBatch pb, int H, int W, int winsize, int iters, double weight_back,
-                                const WarpMode& wm)
-{
-    const int L = (int)lv.size() - 1;
-    float* fp = (float*)h->flow_pyr.p;
-    const int n2 = 2 * pb.npairs;
-    const float* fin = prev;
-    int ch = 0, cw = 0;
-    if (L > 0) {
-        fin = nullptr;
-        if (prev) {
-            float* a = fp + lv[L].f_off;
-            ScopedTimer t(h, FDN_TIMER_PERMUTE);
-            if (resize_dev(h, prev, H, W, a, lv[L].h, lv[L].w, 2, n2, 3, true, lv[L].scale)) return -1;
-            fin = a;
-        }
-        for (int k = L; k >= 1; k--) {
-            float* b = fp + lv[k].f_off + (size_t)n2 * lv[k].h * lv[k].w * 2;
-            ScopedTimer t(h, FDN_TIMER_FUSED);
-            launch_farneback_fused_two((const float*)h->Rpyr.p + lv[k].r_off, nullptr, fin, b, nullptr, nullptr, pb, lv[k].h, lv[k].w,
-                                       winsize, iters, 0.0, h->stream, h->tn, ch, cw);
-            fin = b; ch = lv[k].h; cw = lv[k].w;
-        }
-    }
-    ScopedTimer t(h, FDN_TIMER_FUSED);
-    launch_farneback_fused_two(R0, stack, fin, out0, acc, fwd_values, pb, H, W, winsize, iters, weight_back, h->stream, h->tn, ch, cw, wm);
     return 0;
 }
 
@@ -771,15 +691,13 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
     if (h->tn.path == 2 && !iter) return fail("path 2 (one-iteration kernels) cannot run winsize %d, iters %d here", p->winsize, p->iters);
     // Scratch of a batch of C target slices, per pixel: the flows (sweep_flow_px) and, when a workspace limit is set, the
     // polynomial expansions too (20 B per slice, 26.7 with a pyramid): R is then rebuilt per batch for its C + 2r slices.
-    const bool two = sweep_two_sided(h, p, path, r);
-    const bool fwd_f64 = wm_all.kind == FDN_WARP_F64_PADDED;
-    const size_t flow_px = sweep_flow_px(path, r, pyramid, two, fwd_f64);
+    const size_t flow_px = sweep_flow_px(path, r, pyramid);
     const size_t r_px = pyramid ? 27 : 20;
     const bool limited = h->ws_limit != 0;
     bool rebuild_r = false;
     int C;
     if (limited) {
-        const size_t other = owned_bytes(h) - (h->R.cap + h->Rpyr.cap + h->pyr_tmp.cap + h->flow.cap + h->M0.cap + h->M1.cap + h->flow_pyr.cap + h->fwd.cap);
+        const size_t other = owned_bytes(h) - (h->R.cap + h->Rpyr.cap + h->pyr_tmp.cap + h->flow.cap + h->M0.cap + h->M1.cap + h->flow_pyr.cap);
         const size_t fixed = (size_t)2 * r * HW * r_px + (pyramid ? std::min<size_t>((size_t)1 << 28, HW * 12 * (size_t)(S + 2 * r)) : 0);   // halo slices' R + blur scratch
         const size_t per_target = HW * (flow_px + r_px);
         if (h->ws_limit < other + fixed + per_target)
@@ -798,7 +716,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
         const size_t r_all = (size_t)(S + 2 * r) * 5 * HW * sizeof(float);
         const size_t pyr_all = pyramid ? (size_t)(S + 2 * r) * HW * 7 + std::min<size_t>((size_t)1 << 30, HW * 12 * (size_t)(S + 2 * r)) : 0;
         const size_t pyr_have = h->Rpyr.cap + h->pyr_tmp.cap;
-        const size_t have = h->flow.cap + h->M0.cap + h->M1.cap + h->flow_pyr.cap + h->fwd.cap;
+        const size_t have = h->flow.cap + h->M0.cap + h->M1.cap + h->flow_pyr.cap;
         // what this call may take: what is free plus what the handle would reuse, less a reserve that stays free whatever
         // happens -- 1/16 of the device and at least 6 GiB: the runtime's own allocations, other handles of the process
         // (the CLI's upload handle, a writer's page-locked mapping), a caller's volumes that come later
@@ -821,11 +739,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
     const int CR = limited || rebuild_r ? C : S;              // target slices per rebuild of R
     if (ensure(h, h->R, (size_t)(CR + 2 * r) * 5 * HW * sizeof(float))) return -1;
     float* R = (float*)h->R.p;
-    if (two) {
-        if (ensure(h, h->flow, (size_t)C * HW * 32)) return -1;
-        if (ensure(h, h->fwd, (size_t)C * HW * r * (fwd_f64 ? 8 : 4))) return -1;
-        if (pyramid && ensure_flow_pyramid(h, lv, 2 * C, 2)) return -1;
-    } else if (fused || iter) {
+    if (fused || iter) {
         if (ensure(h, h->flow, (size_t)C * HW * 16)) return -1;
         if (pyramid && ensure_flow_pyramid(h, lv, C, 2)) return -1;
     } else {
@@ -860,34 +774,6 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
         int n = std::min(C, nr - c0);
         float* acc = out + (size_t)c0 * HW;
         launch_fill(acc, 0.f, (size_t)n * HW, st);
-        if (two) {
-            // both sides of chain step a = 1 .. r in one launch per Farneback iteration (seq:95-98 and 110-113 are the same
-            // recurrence on mirrored pairs); the back side folds in as it goes, the forward side's warped values wait for
-            // the centre tap (seq:108), then fold in nearest first -- seq:95-122's order
-            float* const bufs[2] = {flow, flow + (size_t)C * HW * 4};
-            const size_t vsz = fwd_f64 ? 8 : 4;
-            const float* prev = nullptr;
-            for (int step = 0; step < r; step++) {
-                const int a = step + 1;
-                const bool keep = p->chained && step + 1 < r;
-                void* fv = (char*)h->fwd.p + (size_t)step * n * HW * vsz;
-                if (fused) {
-                    float* fout = prev == bufs[0] ? bufs[1] : bufs[0];
-                    if (chain_step_fused_two(h, lv, R, stack, prev, keep ? fout : nullptr, acc, fv, PairBatch{n, r + c0, a}, H, W,
-                                             p->winsize, p->iters, kernel[r - a], wm)) return -1;
-                    prev = keep ? fout : nullptr;
-                    continue;
-                }
-                float* res = nullptr;
-                if (chain_step_iter_two(h, lv, R, stack, prev, bufs, acc, fv, PairBatch{n, r + c0, a}, H, W,
-                                        p->winsize, p->iters, kernel[r - a], keep, &res, wm)) return -1;
-                prev = keep ? res : nullptr;
-            }
-            ScopedTimer t(h, FDN_TIMER_WARP);
-            if (launch_fold_forward(stack + (size_t)(r + c0) * HW, h->fwd.p, fwd_f64, acc, (size_t)n * HW, (size_t)n * HW, r, kernel[r], kernel + r + 1, st))
-                return fail("k_fold_forward could not be launched");
-            continue;
-        }
         for (int side = 0; side < 2; side++) {
             if (side == 1) launch_axpy_slices(stack, acc, PairBatch{n, r + c0, 0}, H, W, kernel[r], st); // seq:108
             if (fused) {
@@ -996,7 +882,7 @@ static int filter_axis_dev(fdn_ctx* h, const float* d_in, float* d_out, int Z, i
         const std::vector<PyrLevel> lv = pyramid_levels(p->use_of ? p->levels : 0, H, W);
         const bool pyr = lv.size() > 1;
         const int spath = sweep_path(h, p, lv, H, W);
-        const size_t sweep_px = !p->use_of ? 0 : (pyr ? 27 : 20) + sweep_flow_px(spath, r, pyr, sweep_two_sided(h, p, spath, r), p->warp_mode == FDN_WARP_F64_PADDED);
+        const size_t sweep_px = !p->use_of ? 0 : (pyr ? 27 : 20) + sweep_flow_px(spath, r, pyr);
         const size_t per_target = HW * (4 + (axis ? 4 : 0) + sweep_px);
         const size_t fixed = (size_t)2 * r * HW * (4 + (p->use_of ? (pyr ? 27 : 20) : 0)) + (pyr ? std::min<size_t>((size_t)1 << 28, HW * 12 * (size_t)(S + 2 * r)) : 0);
         if (h->ws_limit < keep + fixed + per_target)
@@ -1409,7 +1295,6 @@ FDN_API int fdn_create(int device, fdn_handle* out)
     h->tn.path = env_int("FDN_FORCE_STAGED") ? 1 : env_int("FDN_PATH");
     h->tn.fused_occ = env_int("FDN_FUSED_OCC");
     h->tn.lds_pad = (unsigned)env_int("FDN_LDS_PAD");
-    if (getenv("FDN_TWO_SIDED")) h->tn.two_sided = env_int("FDN_TWO_SIDED") & 3;
     if (const char* tp = getenv("FDN_LAUNCH_TRACE")) h->trace_fd = open(tp, O_CREAT | O_WRONLY | O_APPEND, 0644);
     *out = h;
     return 0;
@@ -1493,8 +1378,7 @@ FDN_API int fdn_set_option(fdn_handle h, const char* name, long value)
     else if (!strcmp(name, "fused_occ")) { if (value && (value < 3 || value > 5) && value != 8) return fail("fused_occ must be 0, 3, 4, 5 or 8"); h->tn.fused_occ = (int)value; }
     else if (!strcmp(name, "lds_pad")) { if (value < 0 || value > 160 * 1024) return fail("lds_pad out of range"); h->tn.lds_pad = (unsigned)value; }
     else if (!strcmp(name, "shard_loopback")) h->tn.shard_loopback = value != 0;
-    else if (!strcmp(name, "two_sided")) { if (value < 0 || value > 3) return fail("two_sided: bit 0 = one-iteration kernel, bit 1 = 3-iteration kernel (0..3)"); h->tn.two_sided = (int)value; }
-    else return fail("unknown option '%s' (strict_order, path, fused_occ, lds_pad, shard_loopback, two_sided)", name);
+    else return fail("unknown option '%s' (strict_order, path, fused_occ, lds_pad, shard_loopback)", name);
     return 0;
 }
 FDN_API int fdn_malloc(fdn_handle h, size_t bytes, void** dptr)

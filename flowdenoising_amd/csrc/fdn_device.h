@@ -400,22 +400,6 @@ static __device__ __forceinline__ float fold_warped(const float* __restrict__ sr
     return (float)((double)acc_old + (double)remap_finish(r) * weight);
 }
 
-// warp_slice(neighbour, flow) alone -- the value fold_warped<WM> weighs: a double in mode 1 (cv2.remap's CV_64F result is
-// not rounded to float), a float otherwise (mode 2: an integer).  (float)((double)acc + (double)warped_value * weight)
-// IS fold_warped: the two-sided chain steps store this for the forward side and fold it in after the centre tap.
-template <int WM> struct WarpedValue { typedef float type; };
-template <> struct WarpedValue<1> { typedef double type; };
-template <int WM>
-static __device__ __forceinline__ typename WarpedValue<WM>::type warped_value(const float* __restrict__ src, int H, int W, int x, int y, float2 f,
-                                                                             bool pad, double pad64, float lo, float hi, bool fixed8 = false)
-{
-    RemapTaps r;
-    remap_issue<false>(src, H, W, x, y, f, r);
-    if constexpr (WM == 1) return remap_finish_f64(r, pad, pad64);
-    else if constexpr (WM == 2) return fixed8 ? remap_finish_u8(r) : fminf(fmaxf(rintf(remap_finish(r)), lo), hi);
-    else return remap_finish(r);
-}
-
 static __device__ __forceinline__ float remap_sample(const float* __restrict__ src, int H, int W, int x, int y, float2 f)
 {
     RemapTaps r;

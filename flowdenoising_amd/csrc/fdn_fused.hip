@@ -96,22 +96,17 @@ static __device__ __forceinline__ void lds_barrier()
 // 17.58 ms per launch, same box) -- the two bands are neighbours in the image and stay in step, so the columns they share
 // and the R1 rows both stream arrive once per CU.
 //
-// TWO (round 5; needs NB = 2): the two halves of the workgroup are not two bands of one pair but the SAME band of the two
-// MIRROR pairs of chain step a = pb.d of both sides (seq:95-98 and 110-113): half 0 runs F = (t, +a), half 1 runs
-// B = (t + a, -a) -- the expansion F streams into its window is the one B reads as R0 and the other way round, and the two
-// march down the rows on one barrier, so each expansion comes from HBM once per workgroup.  B folds its warped neighbour
-// into the accumulator as always (back side, nearest first); F stores the warped VALUE (fwd_values) and k_fold_forward
-// adds it after the centre tap: seq:106-122's order, operation for operation.  (fdn_iter.hip's TWO is the same scheme.)
-template <int MH, int D, int DX, int U, int OCC, int FIN, bool ACC, int NB, int WM = 0, bool TWO = false>
+// (Round 5 also built "both sides of a chain step in one launch, mirror pairs in one workgroup" on top of NB = 2: bit-equal,
+// half the HBM bytes per launch and 7.7 % slower -- eight waves on one barrier.  Removed in round 6; the build is kept as
+// profiles/history/r06_two_sided_removed.patch, the measurements in profiles/history/NOTES_r05.md.)
+template <int MH, int D, int DX, int U, int OCC, int FIN, bool ACC, int NB, int WM = 0>
 // (the second argument of __launch_bounds__ is waves per SIMD: for a 4-wave workgroup that is workgroups per CU; the
 // 8-wave workgroup runs two per CU, i.e. the same 4)
 __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused(const float* __restrict__ Rstack, const float* __restrict__ stack,
                                                          const float* __restrict__ flow_in_base, float* __restrict__ flow_out_base,
                                                          float* __restrict__ acc_base, PairBatch pb, int H, int W,
-                                                         double scale, double weight, int nbands, FlowSource fs, WarpMode wm,
-                                                         void* __restrict__ fwd_values)
+                                                         double scale, double weight, int nbands, FlowSource fs, WarpMode wm)
 {
-    static_assert(!TWO || NB == 2, "the two-sided build pairs the two halves of an eight-wave workgroup");
     constexpr int ITERS = 3;
     constexpr int STEP = MH + 1;                 // row stagger between stages
     constexpr int RSD = 2 * MH + 2;              // rows y-MH-1 .. y+MH of M_{K-1} a consumer holds in VGPRs
@@ -156,22 +151,14 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
     // their 12 halo columns and their rows in time -- behind one L2.  Speed only, never correctness.
     const long nwg = gridDim.x, q8 = nwg >> 3, rem8 = nwg & 7;
     const long xcd = blockIdx.x & 7;
-    long gw = (xcd * q8 + (xcd < rem8 ? xcd : rem8) + (blockIdx.x >> 3)) * (TWO ? 1 : NB) + (TWO ? 0 : half);   // a bijection on [0, NB nwg)
+    long gw = (xcd * q8 + (xcd < rem8 ? xcd : rem8) + (blockIdx.x >> 3)) * NB + half;   // a bijection on [0, NB nwg)
     const long nband_total = (long)nbands * pb.npairs;
     const bool live = gw < nband_total;          // NB = 2 and an odd number of bands: the last half repeats a band, stores off
     if (!live) gw = nband_total - 1;
     const int bw = (int)(gw / nbands);              // position in the walk over the pairs (pair_walk: chains of stride |d|)
     const int band = (int)(gw - (long)bw * nbands);
-    // TWO: pb.d = a > 0; the workgroup holds F = (bF, +a) and B = (bF + a, -a) -- at the end of a chain the chain's first B
-    const int bF = pair_walk(bw, pb.npairs, pb.d);
-    const int b = !TWO || half == 0 ? bF : (bF + pb.d < pb.npairs ? bF + pb.d : bF % pb.d);
-    const int pd = TWO ? (half ? -pb.d : pb.d) : pb.d;      // this half's neighbour offset
-    if (TWO) {       // the sides' flows are [F pairs][B pairs] in one buffer
-        const size_t pairs = (size_t)half * pb.npairs;
-        if (FIN == 1) flow_in_base += pairs * (size_t)H * W * 2;
-        if (FIN == 2) flow_in_base += pairs * (size_t)fs.h * fs.w * 2;
-        if (flow_out_base) flow_out_base += pairs * (size_t)H * W * 2;
-    }
+    const int b = pair_walk(bw, pb.npairs, pb.d);
+    const int pd = pb.d;                         // neighbour offset
     const int xb = band * BW - HALO;            // column of lane 0
     const int x = xb + lane;
     const int xc = clampi(x, 0, W - 1);
@@ -389,7 +376,7 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
                     // final stage: the accumulator does not depend on this step's flow: load it first
                     float acc_old = 0.f;
                     const unsigned o = (unsigned)y * (unsigned)W + (unsigned)xc;
-                    if (ACC && K == ITERS && !(TWO && half == 0)) acc_old = ld_off<float>(acc, o * 4u);
+                    if (ACC && K == ITERS) acc_old = ld_off<float>(acc, o * 4u);
                     if (y == 0) { // vsum before row 0: f32(M[0]*(m+2)) + rows 1..m-1 (clamped)
 #pragma unroll
                         for (int c = 0; c < 5; c++) {
@@ -434,19 +421,10 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
                             // (WM: the dtype semantics of an integer volume, fold_warped in fdn_device.h; the neighbour's stack index decides `pad`)
                             const int q = pb.t0 + b + pd;
                             const bool pad = WM == 1 && (q < wm.pad_lo || q >= wm.pad_hi);
-                            if (TWO && half == 0) {        // F: the warped value itself, folded in after the centre tap (k_fold_forward)
-                                typedef typename WarpedValue<WM>::type V;
-                                const V v = warped_value<WM>(img1, H, W, xc, y, f, pad, wm.pad64, wm.lo, wm.hi, wm.fixed8 != 0);
-                                if (owner) {
-                                    if (flow_out) st_off(flow_out, o * 8u, f);
-                                    ((V*)fwd_values)[(size_t)b * HW + o] = v;
-                                }
-                            } else {
-                                const float acc_new = fold_warped<WM>(img1, H, W, xc, y, f, acc_old, weight, pad, wm.pad64, wm.lo, wm.hi, wm.fixed8 != 0);
-                                if (owner) {
-                                    if (flow_out) st_off(flow_out, o * 8u, f);
-                                    st_off(acc, o * 4u, acc_new);
-                                }
+                            const float acc_new = fold_warped<WM>(img1, H, W, xc, y, f, acc_old, weight, pad, wm.pad64, wm.lo, wm.hi, wm.fixed8 != 0);
+                            if (owner) {
+                                if (flow_out) st_off(flow_out, o * 8u, f);
+                                st_off(acc, o * 4u, acc_new);
                             }
                         } else if (owner) {      // a coarser pyramid level: the flow is the result
                             st_off(flow_out, o * 8u, f);
@@ -508,10 +486,9 @@ template <> struct FusedVariant<1, 4> { static constexpr int D = 7, DX = 5, U = 
 template <> struct FusedVariant<3, 4> { static constexpr int D = 6, DX = 5, U = 4; };   // 46 useful columns per band
 template <> struct FusedVariant<4, 3> { static constexpr int D = 7, DX = 6, U = 2; };   // 40 useful columns per band
 
-template <int MH, int OCC, int NB = 1, bool TWO = false>
+template <int MH, int OCC, int NB = 1>
 static void launch_variant(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
-                           PairBatch pb, int H, int W, double scale, double weight, FlowSource fs, hipStream_t st, unsigned lds_pad, const WarpMode& wm,
-                           void* fwd_values = nullptr)
+                           PairBatch pb, int H, int W, double scale, double weight, FlowSource fs, hipStream_t st, unsigned lds_pad, const WarpMode& wm)
 {
     constexpr int D = FusedVariant<MH, OCC>::D, DX = FusedVariant<MH, OCC>::DX, U = FusedVariant<MH, OCC>::U;
     constexpr int WC = 64 + 2 * DX, WCP = FDN_WIN_QUAD ? WC : (5 * WC) % 16 == 0 ? WC + 2 : WC;   // as in the kernel
@@ -520,7 +497,7 @@ static void launch_variant(const float* Rstack, const float* stack, const float*
     static_assert(win_bytes + 3 * 2 * 5 * 64 * sizeof(float) <= (160 * 1024 / OCC) / 2048 * 2048, "LDS per workgroup");
     const int BW = 64 - 2 * MH * 3;
     const int nbands = (W + BW - 1) / BW;
-    dim3 grid((unsigned)(TWO ? (long)nbands * pb.npairs : ((long)nbands * pb.npairs + NB - 1) / NB));
+    dim3 grid((unsigned)(((long)nbands * pb.npairs + NB - 1) / NB));
     auto launch = [&](auto kern) {
         const unsigned lds = NB * win_bytes + (NB == 1 ? lds_pad : 0);     // lds_pad: an occupancy experiment knob of the one-band build
         if (lds > 64 * 1024) {      // above 64 KB of dynamic LDS a kernel must be told so: once per kernel, device and host thread
@@ -535,25 +512,25 @@ static void launch_variant(const float* Rstack, const float* stack, const float*
                 told.push_back(key);
             }
         }
-        hipLaunchKernelGGL(kern, grid, dim3(256 * NB), lds, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, fs, wm, fwd_values);
+        hipLaunchKernelGGL(kern, grid, dim3(256 * NB), lds, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, nbands, fs, wm);
     };
     const int fin = !flow_in ? 0 : fs.h > 0 ? 2 : 1;
     if (acc && wm.kind == 1) {          // integer volumes (fdn_sweep_params.warp_mode): the accumulate in their own semantics
-        if (fin == 2) launch(k_farneback_fused<MH, D, DX, U, OCC, 2, true, NB, 1, TWO>);
-        else if (fin == 1) launch(k_farneback_fused<MH, D, DX, U, OCC, 1, true, NB, 1, TWO>);
-        else launch(k_farneback_fused<MH, D, DX, U, OCC, 0, true, NB, 1, TWO>);
+        if (fin == 2) launch(k_farneback_fused<MH, D, DX, U, OCC, 2, true, NB, 1>);
+        else if (fin == 1) launch(k_farneback_fused<MH, D, DX, U, OCC, 1, true, NB, 1>);
+        else launch(k_farneback_fused<MH, D, DX, U, OCC, 0, true, NB, 1>);
     } else if (acc && wm.kind == 2) {
-        if (fin == 2) launch(k_farneback_fused<MH, D, DX, U, OCC, 2, true, NB, 2, TWO>);
-        else if (fin == 1) launch(k_farneback_fused<MH, D, DX, U, OCC, 1, true, NB, 2, TWO>);
-        else launch(k_farneback_fused<MH, D, DX, U, OCC, 0, true, NB, 2, TWO>);
+        if (fin == 2) launch(k_farneback_fused<MH, D, DX, U, OCC, 2, true, NB, 2>);
+        else if (fin == 1) launch(k_farneback_fused<MH, D, DX, U, OCC, 1, true, NB, 2>);
+        else launch(k_farneback_fused<MH, D, DX, U, OCC, 0, true, NB, 2>);
     } else if (acc) {
-        if (fin == 2) launch(k_farneback_fused<MH, D, DX, U, OCC, 2, true, NB, 0, TWO>);
-        else if (fin == 1) launch(k_farneback_fused<MH, D, DX, U, OCC, 1, true, NB, 0, TWO>);
-        else launch(k_farneback_fused<MH, D, DX, U, OCC, 0, true, NB, 0, TWO>);
+        if (fin == 2) launch(k_farneback_fused<MH, D, DX, U, OCC, 2, true, NB, 0>);
+        else if (fin == 1) launch(k_farneback_fused<MH, D, DX, U, OCC, 1, true, NB, 0>);
+        else launch(k_farneback_fused<MH, D, DX, U, OCC, 0, true, NB, 0>);
     } else {
-        if (fin == 2) launch(k_farneback_fused<MH, D, DX, U, OCC, 2, false, NB, 0, TWO>);
-        else if (fin == 1) launch(k_farneback_fused<MH, D, DX, U, OCC, 1, false, NB, 0, TWO>);
-        else launch(k_farneback_fused<MH, D, DX, U, OCC, 0, false, NB, 0, TWO>);
+        if (fin == 2) launch(k_farneback_fused<MH, D, DX, U, OCC, 2, false, NB, 0>);
+        else if (fin == 1) launch(k_farneback_fused<MH, D, DX, U, OCC, 1, false, NB, 0>);
+        else launch(k_farneback_fused<MH, D, DX, U, OCC, 0, false, NB, 0>);
     }
 }
 
@@ -597,21 +574,6 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
         else launch_variant<2, 4>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad, wm);
         break;
     }
-}
-
-// Both sides of chain step pb.d = a > 0 in one launch (the TWO build, see the kernel): flow_in / flow_out hold
-// [F pairs][B pairs]; acc != nullptr: B folds into acc with `weight`, F stores its warped values to fwd_values.
-// Windows of winsize 4-5 only (the build with an eight-wave workgroup); false: not available for this window.
-bool fused_two_supported(int winsize) { return winsize / 2 == 2; }
-void launch_farneback_fused_two(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc, void* fwd_values,
-                                PairBatch pb, int H, int W, int winsize, int iters, double weight, hipStream_t st,
-                                const Tuning& tn, int coarse_h, int coarse_w, const WarpMode& wm)
-{
-    if (pb.npairs <= 0 || pb.d <= 0) return;
-    (void)iters;
-    FlowSource fs{coarse_h, coarse_w, coarse_h > 0 ? (double)coarse_w / W : 1.0, coarse_h > 0 ? (double)coarse_h / H : 1.0};
-    const double scale = 1. / ((double)winsize * winsize);
-    launch_variant<2, 4, 2, true>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad, wm, fwd_values);
 }
 
 } // namespace fdn

@@ -87,9 +87,6 @@ struct Tuning {
     unsigned lds_pad = 0;    // FDN_LDS_PAD: extra dynamic LDS per workgroup (occupancy curves)
     int cus = 256;           // compute units of the handle's device
     int shard_loopback = 0;  // fdn_filter_3d_sharded: the blocks a rank keeps also travel through the transport (send to self)
-    int two_sided = 0;       // FDN_TWO_SIDED: both sides of a chain step in one launch, mirror pairs in one workgroup: bit 0 = on the
-                             // one-iteration kernel, bit 1 = on the 3-iteration kernel (winsize 4-5); 0 (default): a launch per side.
-                             // Measured in round 5: it halves the HBM traffic of a launch and buys no time
 };
 
 // Fused chain step (fdn_fused.hip): for every pair of the batch, the whole level-0 Farneback
@@ -101,13 +98,6 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
                             float* acc, PairBatch pb, int H, int W, int winsize, int iters, double weight,
                             hipStream_t st, const Tuning& tn, int coarse_h = 0, int coarse_w = 0, const WarpMode& wm = WarpMode());
 
-// The same for BOTH sides of chain step pb.d = a > 0 (mirror pairs share a workgroup; winsize 4-5): flows as [F pairs][B pairs],
-// the back side folds into acc, the forward side's warped values go to fwd_values for launch_fold_forward.
-bool fused_two_supported(int winsize);
-void launch_farneback_fused_two(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc, void* fwd_values,
-                                PairBatch pb, int H, int W, int winsize, int iters, double weight, hipStream_t st,
-                                const Tuning& tn, int coarse_h = 0, int coarse_w = 0, const WarpMode& wm = WarpMode());
-
 // One Farneback iteration per launch, any window (fdn_iter.hip): flow_out = solve(box_w(UpdateMatrices(flow_in)));
 // acc != nullptr: also acc += weight * remap(stack[n], flow_out) (the last iteration of the finest level; flow_out may
 // then be nullptr).  flow_in nullptr = zero flow; coarse_h/w > 0: flow_in is the next coarser level's flow of that size.
@@ -117,16 +107,6 @@ size_t iter_lds_bytes(int mh, bool acc);
 int launch_farneback_iter(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
                           PairBatch pb, int H, int W, int winsize, double weight, hipStream_t st,
                           int coarse_h = 0, int coarse_w = 0, const WarpMode& wm = WarpMode());
-
-// Both sides of chain step pb.d = a > 0 in one launch (fdn_iter.hip, "TWO"): flows as [F pairs][B pairs]; the back side
-// folds into acc, the forward side's warped values go to fwd_values for launch_fold_forward.
-int launch_farneback_iter_two(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc, void* fwd_values,
-                              PairBatch pb, int H, int W, int winsize, double weight, hipStream_t st,
-                              int coarse_h = 0, int coarse_w = 0, const WarpMode& wm = WarpMode());
-struct FoldWeights { static constexpr int MAX = 64; double w[MAX]; };
-// acc = centre tap, then the r stored forward values (step s at values + s * step_stride), nearest first (seq:108-122)
-int launch_fold_forward(const float* centre, const void* values, bool values_f64, float* acc, size_t count, size_t step_stride, int r,
-                        double wc, const double* weights, hipStream_t st);
 
 // where the fused kernel's initial flow comes from when it is the next coarser pyramid level's result
 struct FlowSource { int h, w; double sx, sy; };   // h == 0: flow_in has the image's own size

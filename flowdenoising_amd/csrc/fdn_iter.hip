@@ -26,18 +26,9 @@
 //   one step ahead, into registers.
 // LDS per workgroup at winsize 15: 20.0 KB ring + 5.3 KB window rows = 25.3 KB -> 6 workgroups = 12 waves per CU.
 //
-// TWO (round 5): BOTH sides of a chain step in one launch, mirror pairs in one workgroup.  seq:95-122 walks, for every
-// target t, the back side t-1, t-2, ... and then the forward side t+1, t+2, ...; step |d| = a of the two sides is the
-// pairs (t, -a) and (t, +a) for all t.  Pair F = (t, +a) reads the expansions R[t] (as R0) and R[t+a] (as R1); pair
-// B = (t+a, -a) reads the same two slices with the roles swapped.  One workgroup runs F and B of one band side by side --
-// waves {0, 1} producers, {2, 3} consumers, {4, 5} warpers, one s_barrier for all -- so the two march down the rows in
-// lock step and whatever row of either expansion one of them fetches, the other one needs within two row steps: it is
-// in L2 (and often in the CU's L1), and each expansion comes from HBM once per workgroup instead of twice.  The order of
-// seq:106-122's accumulation is kept exactly: B's warped neighbour folds into the accumulator in this launch as before
-// (back side, nearest first), F's warped VALUE goes to a buffer (4 B per pixel instead of an accumulator read + write:
-// the same bytes) and is folded in after the centre tap by k_fold_forward, nearest first -- the same operations on the
-// same operands in the same order.  Chains end somewhere: the last F of a chain shares its workgroup with the chain's
-// first B (no common slice, same code).
+// (Round 5 also ran BOTH sides of a chain step in one launch, mirror pairs in one workgroup: bit-equal, half the HBM bytes
+// of the warping launch and no faster -- this kernel is paced by the CU's L1 path, not by HBM.  Removed in round 6:
+// profiles/history/r06_two_sided_removed.patch, measurements in profiles/history/NOTES_r05.md.)
 #include "fdn_internal.h"
 #include "fdn_device.h"
 #include <algorithm>
@@ -86,24 +77,19 @@ static __device__ __forceinline__ void lds_barrier_iter()
 // MHT: window half-width when known at compile time (0: runtime mh).  FIN 0: zero initial flow, 1: flow_in has the
 // image's size, 2: flow_in is the next coarser level's (fs.h x fs.w) result, resized INTER_LINEAR and doubled on the fly
 // (calc()'s upsampling).  ACC: also warp the neighbour with the new flow and accumulate.
-template <int MHT, int FIN, bool ACC, int WM = 0, bool TWO = false>
-__global__ __launch_bounds__((ACC ? 192 : 128) * (TWO ? 2 : 1)) void k_farneback_iter(const float* __restrict__ Rstack, const float* __restrict__ stack,
+template <int MHT, int FIN, bool ACC, int WM = 0>
+__global__ __launch_bounds__(ACC ? 192 : 128) void k_farneback_iter(const float* __restrict__ Rstack, const float* __restrict__ stack,
                                                         const float* __restrict__ flow_in_base, float* __restrict__ flow_out_base,
                                                         float* __restrict__ acc_base, PairBatch pb, int H, int W, int mh_rt,
-                                                        double scale, double weight, int nbands, FlowSource fs, WarpMode wm,
-                                                        void* __restrict__ fwd_values)
+                                                        double scale, double weight, int nbands, FlowSource fs, WarpMode wm)
 {
     const int MH = MHT ? MHT : mh_rt;
     const int RS = 2 * MH + 2;
     const int BW = 64 - 2 * MH;
     const int WP = window_block(2 * MH + 1), WQ = (2 * MH + 1) / WP, WREM = 2 * MH + 1 - WP * WQ, WE = MH % WP;
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
-    // TWO: wave w works for pair (w & 1) -- 0: F = (target, +a), 1: B = (its mirror target, -a) -- in role w >> 1; each pair
-    // has its own ring, window rows and flow slots
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int sel = TWO ? (wave & 1) : 0;
-    const int role = TWO ? (wave >> 1) : wave;
-    float* lds = lds_all + (TWO ? (size_t)sel * (((size_t)RS * 320 * sizeof(float) + (size_t)2 * (5 * 64 + 2 * MH + 2) * sizeof(double) + (ACC ? 2 * 64 * sizeof(float2) : 0)) / sizeof(float)) : 0);
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave 0: producer, 1: consumer, 2: warper
+    float* lds = lds_all;
     // ring row: [ (m0, m2) x 64 ][ (m3, m4) x 64 ][ m1 x 64 ] floats; then the consumer's window row: 5 x (64 + 2 MH) doubles
     float* ring = lds;
     // the window rows (see the consumer): [2][XR] doubles, channel c's lane L at MH + 64 c + L.  Reads run up to MH
@@ -121,17 +107,8 @@ __global__ __launch_bounds__((ACC ? 192 : 128) * (TWO ? 2 : 1)) void k_farneback
     const long gw = xcd * q8 + (xcd < rem8 ? xcd : rem8) + (blockIdx.x >> 3);
     const int bw = (int)(gw / nbands);              // position in the walk over the pairs (pair_walk: chains of stride |d|)
     const int band = (int)(gw - (long)bw * nbands);
-    // TWO: pb.d = a > 0; workgroup bw of the walk holds F = (bF, +a) and B = (bF + a, -a), or -- at the end of a chain --
-    // the chain's first target's B (bF % a; bF itself when a >= npairs)
-    const int bF = pair_walk(bw, pb.npairs, pb.d);
-    const int b = !TWO || sel == 0 ? bF : (bF + pb.d < pb.npairs ? bF + pb.d : bF % pb.d);
-    const int d = TWO ? (sel ? -pb.d : pb.d) : pb.d;
-    if (TWO) {       // the sides' flows are [side][pair] in one buffer: F first
-        const size_t pairs = (size_t)sel * pb.npairs;
-        if (FIN == 1) flow_in_base += pairs * (size_t)H * W * 2;
-        if (FIN == 2) flow_in_base += pairs * (size_t)fs.h * fs.w * 2;
-        if (flow_out_base) flow_out_base += pairs * (size_t)H * W * 2;
-    }
+    const int b = pair_walk(bw, pb.npairs, pb.d);
+    const int d = pb.d;
     const int xb = band * BW - MH;
     const int x = xb + lane;
     const int xc = clampi(x, 0, W - 1);       // lanes outside the image replicate the border column (BORDER_REPLICATE of vsum)
@@ -220,16 +197,9 @@ __global__ __launch_bounds__((ACC ? 192 : 128) * (TWO ? 2 : 1)) void k_farneback
                 const unsigned o = (unsigned)y * (unsigned)W + (unsigned)xc;
                 const int q = pb.t0 + b + d;           // (WM: integer-volume semantics, warped_value in fdn_device.h)
                 const bool pad = WM == 1 && (q < wm.pad_lo || q >= wm.pad_hi);
-                if (TWO && sel == 0) {
-                    // F side: the warped value itself, folded in after the centre tap (k_fold_forward) -- seq:110-122's order
-                    typedef typename WarpedValue<WM>::type V;
-                    const V v = warped_value<WM>(img1, H, W, xc, y, f, pad, wm.pad64, wm.lo, wm.hi, wm.fixed8 != 0);
-                    if (owner) ((V*)fwd_values)[(size_t)b * HW + o] = v;
-                } else {
-                    const float acc_old = ld_off<float>(acc, o * 4u);
-                    const float acc_new = fold_warped<WM>(img1, H, W, xc, y, f, acc_old, weight, pad, wm.pad64, wm.lo, wm.hi, wm.fixed8 != 0);
-                    if (owner) st_off(acc, o * 4u, acc_new);
-                }
+                const float acc_old = ld_off<float>(acc, o * 4u);
+                const float acc_new = fold_warped<WM>(img1, H, W, xc, y, f, acc_old, weight, pad, wm.pad64, wm.lo, wm.hi, wm.fixed8 != 0);
+                if (owner) st_off(acc, o * 4u, acc_new);
             }
             lds_barrier_iter();
         }
@@ -269,7 +239,7 @@ __global__ __launch_bounds__((ACC ? 192 : 128) * (TWO ? 2 : 1)) void k_farneback
             //     B[L] = v[L-e] + ... + v[L-e+p-1]                (p consecutive columns, left to right; e = MH % p)
             //     window[L] = B[L-MH+e] + B[L-MH+e+p] + ... (q blocks, left to right) + v[L+MH-rem+1] + ... + v[L+MH]
             // e places one of the q blocks at offset 0 and the lane's own column inside B: both come from registers.
-            // winsize 15: p = 3, q = 5: 2 + 4 LDS reads, 2 writes and 6 additions per channel in TWO write -> read round
+            // winsize 15: p = 3, q = 5: 2 + 4 LDS reads, 2 writes and 6 additions per channel in two write -> read round
             // trips.  (The consumer's row step is a chain of dependent LDS round trips, and that chain -- not the
             // operation count -- is what the step waits for: summing the window by doubling, T2k[L] = Tk[L] + Tk[L+k],
             // takes 7 reads, 4 writes, 6 additions but FOUR round trips: 16 % slower, 1.84 against 1.55 s per -l 3 -w 15
@@ -357,14 +327,14 @@ size_t iter_lds_bytes(int mh, bool acc)
     return (size_t)(2 * mh + 2) * 320 * sizeof(float) + (size_t)2 * (5 * 64 + 2 * mh + 2) * sizeof(double) + (acc ? 2 * 64 * sizeof(float2) : 0);
 }
 
-template <int MHT, bool TWO>
+template <int MHT>
 static int launch_iter_t(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc, PairBatch pb,
-                         int H, int W, int mh, double scale, double weight, FlowSource fs, hipStream_t st, const WarpMode& wm, void* fwd_values)
+                         int H, int W, int mh, double scale, double weight, FlowSource fs, hipStream_t st, const WarpMode& wm)
 {
     const int BW = 64 - 2 * mh;
     const int nbands = (W + BW - 1) / BW;
     dim3 grid((unsigned)((long)nbands * pb.npairs));
-    const size_t lds = iter_lds_bytes(mh, acc != nullptr) * (TWO ? 2 : 1);
+    const size_t lds = iter_lds_bytes(mh, acc != nullptr);
     const int fin = !flow_in ? 0 : fs.h > 0 ? 2 : 1;
     auto launch = [&](auto kern) -> int {
         if (lds > 48 * 1024) {      // a kernel must be told (per device and host thread) that it may take that much dynamic LDS:
@@ -378,45 +348,28 @@ static int launch_iter_t(const float* Rstack, const float* stack, const float* f
                 if (it == told.end()) told.push_back(Told{(const void*)kern, dev, lds}); else it->bytes = lds;
             }
         }
-        hipLaunchKernelGGL(kern, grid, dim3((acc ? 192 : 128) * (TWO ? 2 : 1)), lds, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight,
-                           nbands, fs, wm, fwd_values);
+        hipLaunchKernelGGL(kern, grid, dim3(acc ? 192 : 128), lds, st, Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight,
+                           nbands, fs, wm);
         return hipGetLastError() == hipSuccess ? 0 : -1;      // a bad launch configuration is this launch's error, not the next check's
     };
     if (acc && wm.kind == 1) {
-        if (fin == 2) return launch(k_farneback_iter<MHT, 2, true, 1, TWO>);
-        if (fin == 1) return launch(k_farneback_iter<MHT, 1, true, 1, TWO>);
-        return launch(k_farneback_iter<MHT, 0, true, 1, TWO>);
+        if (fin == 2) return launch(k_farneback_iter<MHT, 2, true, 1>);
+        if (fin == 1) return launch(k_farneback_iter<MHT, 1, true, 1>);
+        return launch(k_farneback_iter<MHT, 0, true, 1>);
     }
     if (acc && wm.kind == 2) {
-        if (fin == 2) return launch(k_farneback_iter<MHT, 2, true, 2, TWO>);
-        if (fin == 1) return launch(k_farneback_iter<MHT, 1, true, 2, TWO>);
-        return launch(k_farneback_iter<MHT, 0, true, 2, TWO>);
+        if (fin == 2) return launch(k_farneback_iter<MHT, 2, true, 2>);
+        if (fin == 1) return launch(k_farneback_iter<MHT, 1, true, 2>);
+        return launch(k_farneback_iter<MHT, 0, true, 2>);
     }
     if (acc) {
-        if (fin == 2) return launch(k_farneback_iter<MHT, 2, true, 0, TWO>);
-        if (fin == 1) return launch(k_farneback_iter<MHT, 1, true, 0, TWO>);
-        return launch(k_farneback_iter<MHT, 0, true, 0, TWO>);
+        if (fin == 2) return launch(k_farneback_iter<MHT, 2, true, 0>);
+        if (fin == 1) return launch(k_farneback_iter<MHT, 1, true, 0>);
+        return launch(k_farneback_iter<MHT, 0, true, 0>);
     }
-    if (fin == 2) return launch(k_farneback_iter<MHT, 2, false, 0, TWO>);
-    if (fin == 1) return launch(k_farneback_iter<MHT, 1, false, 0, TWO>);
-    return launch(k_farneback_iter<MHT, 0, false, 0, TWO>);
-}
-
-template <bool TWO>
-static int launch_iter_any(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
-                           PairBatch pb, int H, int W, int winsize, double weight, hipStream_t st, int coarse_h, int coarse_w, const WarpMode& wm,
-                           void* fwd_values)
-{
-    if (pb.npairs <= 0) return 0;
-    FlowSource fs{coarse_h, coarse_w, coarse_h > 0 ? (double)coarse_w / W : 1.0, coarse_h > 0 ? (double)coarse_h / H : 1.0};
-    const double scale = 1. / ((double)winsize * winsize);
-    const int mh = winsize / 2;
-    switch (mh) {   // compile-time windows for the usual sizes; anything else takes the runtime-width build
-    case 2: return launch_iter_t<2, TWO>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st, wm, fwd_values);
-    case 5: return launch_iter_t<5, TWO>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st, wm, fwd_values);
-    case 7: return launch_iter_t<7, TWO>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st, wm, fwd_values);
-    default: return launch_iter_t<0, TWO>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st, wm, fwd_values);
-    }
+    if (fin == 2) return launch(k_farneback_iter<MHT, 2, false, 0>);
+    if (fin == 1) return launch(k_farneback_iter<MHT, 1, false, 0>);
+    return launch(k_farneback_iter<MHT, 0, false, 0>);
 }
 
 // One iteration for every pair of the batch.  flow_in: nullptr = zero flow; coarse_h, coarse_w > 0: flow_in is the next
@@ -425,43 +378,16 @@ static int launch_iter_any(const float* Rstack, const float* stack, const float*
 int launch_farneback_iter(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
                           PairBatch pb, int H, int W, int winsize, double weight, hipStream_t st, int coarse_h, int coarse_w, const WarpMode& wm)
 {
-    return launch_iter_any<false>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, winsize, weight, st, coarse_h, coarse_w, wm, nullptr);
-}
-
-// The same for BOTH sides of chain step pb.d = a > 0 at once: pairs (t, +a) ("F") and (t, -a) ("B") of the pb.npairs targets,
-// mirror pairs sharing a workgroup (see the top of this file).  flow_in / flow_out hold [F pairs][B pairs] (2 npairs images);
-// acc != nullptr: B folds into acc with `weight`, F stores its warped values to fwd_values (float, double in warp mode 1).
-int launch_farneback_iter_two(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc, void* fwd_values,
-                              PairBatch pb, int H, int W, int winsize, double weight, hipStream_t st, int coarse_h, int coarse_w, const WarpMode& wm)
-{
-    if (pb.d <= 0) return -1;
-    return launch_iter_any<true>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, winsize, weight, st, coarse_h, coarse_w, wm, fwd_values);
-}
-
-// acc = f32(f64(acc) + f64(centre) wc), then for s = 0 .. r-1: acc = f32(f64(acc) + f64(values[s]) w[s]) -- the centre tap
-// (seq:108) and the forward side of seq:110-122, nearest neighbour first, from the values the two-sided launches stored.
-template <typename V>
-__global__ __launch_bounds__(256) void k_fold_forward(const float* __restrict__ centre, const V* __restrict__ values, float* __restrict__ acc,
-                                                     size_t count, size_t step_stride, int r, double wc, FoldWeights w)
-{
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
-        float a = acc[i];
-        a = (float)((double)a + (double)centre[i] * wc);
-        for (int s = 0; s < r; s++) a = (float)((double)a + (double)values[(size_t)s * step_stride + i] * w.w[s]);
-        acc[i] = a;
+    if (pb.npairs <= 0) return 0;
+    FlowSource fs{coarse_h, coarse_w, coarse_h > 0 ? (double)coarse_w / W : 1.0, coarse_h > 0 ? (double)coarse_h / H : 1.0};
+    const double scale = 1. / ((double)winsize * winsize);
+    const int mh = winsize / 2;
+    switch (mh) {   // compile-time windows for the usual sizes; anything else takes the runtime-width build
+    case 2: return launch_iter_t<2>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st, wm);
+    case 5: return launch_iter_t<5>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st, wm);
+    case 7: return launch_iter_t<7>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st, wm);
+    default: return launch_iter_t<0>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, mh, scale, weight, fs, st, wm);
     }
-}
-
-int launch_fold_forward(const float* centre, const void* values, bool values_f64, float* acc, size_t count, size_t step_stride, int r,
-                        double wc, const double* weights, hipStream_t st)
-{
-    if (r > FoldWeights::MAX) return -1;
-    FoldWeights w;
-    for (int s = 0; s < r; s++) w.w[s] = weights[s];
-    const unsigned blocks = (unsigned)std::min<size_t>((count + 255) / 256, (size_t)256 * 32);
-    if (values_f64) hipLaunchKernelGGL(k_fold_forward<double>, dim3(blocks), dim3(256), 0, st, centre, (const double*)values, acc, count, step_stride, r, wc, w);
-    else hipLaunchKernelGGL(k_fold_forward<float>, dim3(blocks), dim3(256), 0, st, centre, (const float*)values, acc, count, step_stride, r, wc, w);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 } // namespace fdn

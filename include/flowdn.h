@@ -112,7 +112,7 @@ int fdn_workspace_bytes(fdn_handle h, size_t* bytes_out);
 int fdn_mem_info(fdn_handle h, size_t* free_out, size_t* total_out);
 
 /* Switches of a live handle (tests and experiments; fdn_create reads the same from the environment:
- * FDN_STRICT_ORDER, FDN_PATH / FDN_FORCE_STAGED, FDN_FUSED_OCC, FDN_LDS_PAD, FDN_TWO_SIDED).  Every path gives the same
+ * FDN_STRICT_ORDER, FDN_PATH / FDN_FORCE_STAGED, FDN_FUSED_OCC, FDN_LDS_PAD).  Every path gives the same
  * bits except strict_order:
  *   "strict_order" 0/1  OpenCV's serial f64 running sum along x in FarnebackUpdateFlow_Blur instead of the
  *                       direct window sum (about 20x slower; errors out, never falls back, when a row does
@@ -124,11 +124,6 @@ int fdn_mem_info(fdn_handle h, size_t* free_out, size_t* total_out);
  *   "shard_loopback" 0/1  fdn_filter_3d_sharded: the blocks a rank keeps for itself travel through the transport too
  *                  (a send to self inside the group; the mean through allgather_host even with one rank), so that
  *                  ONE rank on one GPU issues the calls of an N > 1 run
- *   "two_sided"    0 (default) one launch per side of a chain step (seq:95-98, then seq:110-113); bit 0 / bit 1: on the
- *                  one-iteration / the 3-iteration Farneback kernel step |d| of BOTH sides runs in one launch, the
- *                  mirror pairs (t, +d) and (t + d, -d) -- which read the same two expansions -- in one workgroup;
- *                  the forward side's warped values are folded in after the centre tap (seq:106-122's order, same
- *                  bits).  Halves the HBM traffic of a launch and buys no time: an option, not the default
  * No counterpart in the reference (cv2 has no such switches). */
 int fdn_set_option(fdn_handle h, const char* name, long value);
 

@@ -982,44 +982,3 @@ def test_cli_gpus_refuses_more_ranks_than_slices_and_a_failing_rank_stops_the_jo
     r = subprocess.run(cli + ["-o", str(tmp_path / "no_such_dir" / "o.mrc"), "--gpus", "2"], env=dict(env, FDN_RDV_TIMEOUT="120"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and time.perf_counter() - t0 < 60, r.stderr[-2000:]
-
-
-# ---- both sides of a chain step in one launch (fdn_set_option two_sided; off by default) ------------------------------------
-@pytest.mark.parametrize("case", [
-    dict(shape=(9, 130, 300), sig=(1.0, None, 1.0), l=0, w=15, border=0),              # one-iteration kernel, chains of four steps
-    dict(shape=(9, 130, 300), sig=(1.0, None, 1.0), l=2, w=11, border=1),              # ... with a pyramid, wrapped ends
-    dict(shape=(3, 70, 160), sig=(1.5, 1.0, None), l=1, w=15, border=0),               # K//2 = 6 > number of targets: every mirror is a chain end
-    dict(shape=(9, 130, 300), sig=(1.0, None, 1.0), l=0, w=5, border=0),               # 3-iteration kernel (the eight-wave mirror build)
-    dict(shape=(8, 90, 200), sig=(1.0, 1.0, 0.5), l=2, w=5, border=1, chained=False),  # ... pyramid, wrap, --recompute_flow
-    dict(shape=(10, 48, 56), sig=(1.0, 1.0, 0.5), l=0, w=5, border=0, dtype=np.int16),   # seq on an integer volume: the forward values are doubles
-    dict(shape=(10, 48, 56), sig=(1.0, 1.0, 0.5), l=1, w=15, border=1, dtype=np.int16),  # par on an integer volume
-    dict(shape=(10, 48, 56), sig=(1.0, 0.5, 1.0), l=0, w=5, border=1, dtype=np.uint8),   # par on uint8: fixed-point remap values
-])
-def test_two_sided_chain_steps_give_the_same_bits(fdn, case):
-    """fdn_set_option("two_sided", 3): step |d| of the back side and of the forward side (seq:95-98, 110-113) in ONE launch,
-    the mirror pairs (t, +d) and (t + d, -d) -- which read the same two expansions -- in one workgroup; the back side folds
-    into the accumulator as it goes, the forward side's warped values wait for the centre tap and are folded in by
-    k_fold_forward, nearest first: seq:106-122's order.  Same bits as one launch per side, on both Farneback kernels, with
-    pyramids, both border rules, integer volumes."""
-    from flowdenoising_amd.operators import handle
-    vol = _vol(case["shape"], seed=91)
-    dt = case.get("dtype")
-    if dt is not None:
-        top = 255 if dt is np.uint8 else 3000
-        vol = np.round((vol - vol.min()) * (top / (vol.max() - vol.min())) - (0 if dt is np.uint8 else 700)).astype(dt)
-    ks = [None if s is None else fdn.get_gaussian_kernel(s) for s in case["sig"]]
-    h = handle()
-    outs = {}
-    try:
-        for two in (0, 3):
-            h.set_option("two_sided", two)
-            h.timers(reset=True)
-            h.enable_timers(True)
-            outs[two] = fdn.OF_filter(vol, ks, case["l"], case["w"], border_mode=case["border"], chained=case.get("chained", True))
-            t = h.timers(reset=True)
-            # the two-sided run really took the other road: its forward side is folded by k_fold_forward ("warp" timer)
-            assert (t["warp"][1] > 0) == (two == 3), (two, t)
-    finally:
-        h.enable_timers(False)
-        h.set_option("two_sided", 0)
-    assert np.array_equal(outs[0], outs[3])

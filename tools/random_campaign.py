@@ -1,8 +1,6 @@
 """One-off randomised parity campaign: many more random sweep configurations than the test suite holds.
-usage: random_campaign.py [n] [seed] [wide|strict|two|widetwo]   -- `wide`: windows 10 .. 31 (the one-iteration kernel) instead of 3 .. 15;
-`strict`: strict_order on (OpenCV's own f64 summation order, segment-walked rows): every case must then be bit-identical;
-`two` / `widetwo`: the two-sided chain steps on (fdn_set_option two_sided = 3: mirror pairs in one workgroup, forward side folded
-afterwards) with the narrow / the wide windows"""
+usage: random_campaign.py [n] [seed] [wide|strict]   -- `wide`: windows 10 .. 31 (the one-iteration kernel) instead of 3 .. 15;
+`strict`: strict_order on (OpenCV's own f64 summation order, segment-walked rows): every case must then be bit-identical"""
 import sys, importlib.util, numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 spec = importlib.util.spec_from_file_location("tp", "tests/test_gpu_parity.py"); tp = importlib.util.module_from_spec(spec); spec.loader.exec_module(tp)
@@ -12,10 +10,7 @@ oracle.build()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 bad = 0; exact = 0; order = 0
 cases = tp._random_cases(n, int(sys.argv[2]) if len(sys.argv) > 2 else 777)
-if len(sys.argv) > 3 and sys.argv[3] in ("two", "widetwo"):
-    from flowdenoising_amd.operators import handle
-    handle().set_option("two_sided", 3)
-if len(sys.argv) > 3 and sys.argv[3] in ("wide", "widetwo"):
+if len(sys.argv) > 3 and sys.argv[3] == "wide":
     rng = np.random.default_rng(99)
     cases = [(shape, axis, l, int(rng.choice([10, 11, 13, 15, 15, 17, 21, 31])), sigma, border, chained, seed)
              for (shape, axis, l, w, sigma, border, chained, seed) in cases]
