@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--engine", choices=("native", "python"), default="native", help="N > 1: fdn_filter_3d_sharded on the native transport "
                     "(libflowdn_rccl.so: RCCL, or shared memory when ranks share a GPU), or the torch.distributed slab engine above the C ABI (distributed.py)")
     ap.add_argument("--path", type=int, default=0, help="fdn_set_option path: 0 auto, 1 staged, 2 per-iteration kernels")
+    ap.add_argument("--sub-batches", type=int, default=0, help="fdn_set_option sub_batches: 0 automatic (two streams on small grids), 1 one stream, 2 two")
     ap.add_argument("--cpu-targets", type=int, default=0, help="target slices of the CPU sample (0 = four per core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check and the sweep-kernel line")
@@ -97,7 +98,7 @@ def compulsory_bytes_per_px(name, K):
     return (3 * 28 + 2 * 68) / 3.0
 
 
-def roofline(timers, nvox, K, levels, run_cfg):
+def roofline(timers, nvox, K, levels, run_cfg, sub_batches=1):
     """The dominant kernel against the HBM peak, priced on the bytes it has to move."""
     names = {"fused": "k_farneback_fused", "iter": "k_farneback_iter", "update_flow": "k_update_flow_scan"}
     best = None
@@ -111,6 +112,18 @@ def roofline(timers, nvox, K, levels, run_cfg):
     # with a pyramid a chain step is one launch (three for `iter`) per level; level k has 4^-k of the pixels
     px_per_launch = nvox * sum(0.25 ** k for k in range(levels + 1)) / (levels + 1)     # pixels x pairs of a launch
     avg_s = ms / cnt * 1e-3
+    concurrent = None
+    if sub_batches > 1 and timers.get("chains", (0, 0))[1]:
+        # The batch's targets ran as sub-batches on two streams: a launch covers 1 / sub_batches of the pixels and the launches
+        # of the two streams overlap, so their own durations add up to more than the wall clock.  Price the kernel on the span
+        # from fork to join instead (FDN_TIMER_CHAINS: HIP events on the main stream; it also holds the centre-tap axpy of
+        # each sub-batch and, with a pyramid, the flow-shrink kernels -- a few per cent, charged to the kernel here): one
+        # "launch" below = the sub_batches concurrent launches of one chain step and level.
+        concurrent = {"sub_batches": sub_batches, "own_launch_ms": round(ms / cnt, 4), "launches_on_both_streams": cnt,
+                      "note": "launches of the two streams overlap: avg_launch_ms = (fork-to-join span of the chains) / (launches / sub_batches)"}
+        cnt = cnt // sub_batches
+        avg_s = timers["chains"][0] / cnt * 1e-3
+        ms = timers["chains"][0]
     bpp = compulsory_bytes_per_px(name, K)
     achieved = bpp * px_per_launch / avg_s / 1e9
     unfused = {"fused": 300.0, "iter": 100.0, "update_flow": (3 * 28 + 2 * 68) / 3.0}[name]
@@ -124,6 +137,8 @@ def roofline(timers, nvox, K, levels, run_cfg):
                                  "note": "SURVEY 8(d) stage list with every named intermediate through HBM; exceeds the "
                                          "peak exactly when fusion removed that traffic -- not an HBM fraction"},
          "traffic": None}
+    if concurrent:
+        r["concurrent_launches"] = concurrent
     t = committed_profile(names[name], run_cfg)
     r["traffic_source"] = t["note"]
     if t.get("bytes_per_px") is not None:
@@ -496,6 +511,8 @@ def run(a, job, fallback):
     #  synchronisation on either side of the timed region)
     if a.path:
         h.set_option("path", a.path)
+    if a.sub_batches:
+        h.set_option("sub_batches", a.sub_batches)
 
     eng = None
     out_slab = None
@@ -580,12 +597,15 @@ def run(a, job, fallback):
     dt = time.perf_counter() - t0
     dt = float(gather_f64([dt]).max())                    # the MAX over ranks
     timers = h.timers() if not a.no_timers else {}
+    sub_batches = h.get_option("last_sub_batches")       # what the last pass of the timed steps ran with (automatic on small grids)
     phases = None
     if world > 1 and not a.no_timers:
         if eng is not None:
             mine = eng.phase_times()          # ms per category on this rank, over the timed steps
         else:                                 # the library's own timer table (HIP events on the stream the work runs on)
-            kern = sum(timers[k][0] for k in ("polyexp", "update_matrices", "update_flow", "warp", "fused", "iter"))
+            # (with sub-batches the launches of the two streams overlap: the fork-to-join span of the chains is what they took)
+            chain = timers["chains"][0] if timers["chains"][1] else timers["fused"][0] + timers["iter"][0]
+            kern = sum(timers[k][0] for k in ("polyexp", "update_matrices", "update_flow", "warp")) + chain
             mine = {"compute": kern, "pack_unpack_permute": timers["permute"][0], "exchange": timers["collective"][0], "mean": timers["mean"][0]}
         names = sorted(mine)
         allr = gather_f64([mine[n] for n in names])
@@ -629,8 +649,9 @@ def run(a, job, fallback):
                              "note": "SURVEY 8(d) bytes of the unfused stage list / wall time; a ratio above 1 = traffic that fusion removed"}
         if timers:
             run_cfg = {"shape": list(shape), "winsize": a.winsize, "levels": a.levels, "sigma": a.sigma if not a.sigmas else a.sigmas, "axes": a.axes}
-            res["roofline"] = roofline(timers, nvox // world, kernel.size, a.levels, run_cfg)
+            res["roofline"] = roofline(timers, nvox // world, kernel.size, a.levels, run_cfg, sub_batches)
             res["kernel_ms_per_step"] = {k: round(v[0] / a.steps, 2) for k, v in timers.items() if v[1]}
+            res["sub_batches"] = sub_batches
         if phases:
             res["phase_ms_per_step_per_rank"] = phases
         if a.integer:

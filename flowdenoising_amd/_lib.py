@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libflowdn.so")
 USE_INITIAL_FLOW = 4
 BORDER_MEAN_PAD = 0
 BORDER_WRAP = 1
-TIMER_NAMES = ("polyexp", "update_matrices", "update_flow", "warp", "permute", "transfer", "fused", "iter", "collective", "mean")
+TIMER_NAMES = ("polyexp", "update_matrices", "update_flow", "warp", "permute", "transfer", "fused", "iter", "collective", "mean", "chains")
 
 
 class FlowdnError(RuntimeError):
@@ -44,7 +44,7 @@ DEPTHS = {np.dtype(np.float32): DEPTH_F32, np.dtype(np.float64): DEPTH_F64, np.d
 # every symbol include/flowdn.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "fdn_create", "fdn_device_count", "fdn_device_pci_id", "fdn_destroy", "fdn_last_error", "fdn_set_stream", "fdn_reset_stream", "fdn_synchronize",
-    "fdn_set_workspace_limit", "fdn_workspace_bytes", "fdn_mem_info", "fdn_set_option", "fdn_malloc", "fdn_free", "fdn_memcpy_h2d", "fdn_memcpy_d2h",
+    "fdn_set_workspace_limit", "fdn_workspace_bytes", "fdn_mem_info", "fdn_set_option", "fdn_get_option", "fdn_malloc", "fdn_free", "fdn_memcpy_h2d", "fdn_memcpy_d2h",
     "fdn_memcpy2d_h2d", "fdn_memcpy2d_d2h", "fdn_host_register", "fdn_host_unregister",
     "fdn_memset_f32", "fdn_gaussian_kernel", "fdn_farneback", "fdn_farneback_strided", "fdn_farneback_dev",
     "fdn_warp", "fdn_warp_strided", "fdn_warp_dev", "fdn_farneback_typed", "fdn_warp_typed",
@@ -354,8 +354,14 @@ class Handle:
         return f.value, t.value
 
     def set_option(self, name, value):
-        """fdn_set_option: "strict_order", "path", "fused_occ", "lds_pad", "shard_loopback" (see include/flowdn.h)."""
+        """fdn_set_option: "strict_order", "path", "fused_occ", "lds_pad", "shard_loopback", "sub_batches" (see include/flowdn.h)."""
         check(self._lib.fdn_set_option(self._h, ctypes.c_char_p(name.encode()), ctypes.c_long(int(value))))
+
+    def get_option(self, name):
+        """fdn_get_option: an option's value; also "last_sub_batches" and "compute_units" (read-only)."""
+        v = ctypes.c_long()
+        check(self._lib.fdn_get_option(self._h, ctypes.c_char_p(name.encode()), ctypes.byref(v)))
+        return v.value
 
     def malloc(self, nbytes):
         p = ctypes.c_void_p()

@@ -170,6 +170,13 @@ struct fdn_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    // Second stream of the handle: a pass over a SMALL grid runs its target slices as two independent sub-batches, one per
+    // stream (sweep_stack), so that the tail of one launch is filled by the other sub-batch's work instead of idling.
+    // Created on first use; forked from / joined into `stream` by the two events.
+    static constexpr int MAX_SUB = 4;
+    hipStream_t aux_stream[MAX_SUB - 1] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_SUB - 1] = {};
+    int last_sub_batches = 1;    // what the last sweep ran with (fdn_get_option "last_sub_batches")
     size_t ws_limit = 0;
     Tuning tn;
     DevBuf R, M0, M1, flow, stack, sweep_out, vol_a, vol_b, partials, pair, vol_in, vol_out;
@@ -220,6 +227,7 @@ static void resolve_stamps(fdn_ctx* h)
 {
     if (h->stamps.empty()) return;
     (void)hipStreamSynchronize(h->stream);
+    for (hipStream_t s : h->aux_stream) if (s) (void)hipStreamSynchronize(s);     // stamps of a sub-batch were recorded there
     for (auto& s : h->stamps) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { h->tms[s.which] += ms; h->tcount[s.which]++; }
@@ -561,10 +569,16 @@ static int pyramid_batch(fdn_ctx* h, const std::vector<PyrLevel>& lv, const floa
 
 // `copies` flow buffers per level k >= 1 (the fused kernel cannot update a flow in place: the bands of
 // one pair run at their own pace and read each other's halo columns)
+// lays `copies` flow buffers of n images per level k >= 1 out from float offset `base` on; returns the end offset
+static size_t flow_pyramid_layout(std::vector<PyrLevel>& lv, int n, int copies, size_t base)
+{
+    size_t total = base;
+    for (size_t k = 1; k < lv.size(); k++) { lv[k].f_off = total; total += (size_t)copies * n * lv[k].h * lv[k].w * 2; }
+    return total;
+}
 static int ensure_flow_pyramid(fdn_ctx* h, std::vector<PyrLevel>& lv, int n, int copies = 1)
 {
-    size_t total = 0;
-    for (size_t k = 1; k < lv.size(); k++) { lv[k].f_off = total; total += (size_t)copies * n * lv[k].h * lv[k].w * 2; }
+    const size_t total = flow_pyramid_layout(lv, n, copies, 0);
     return ensure(h, h->flow_pyr, std::max<size_t>(total, 1) * sizeof(float));
 }
 
@@ -652,6 +666,68 @@ static int chain_step_iter(fdn_ctx* h, const std::vector<PyrLevel>& lv, const fl
     }
     *result = const_cast<float*>(fin);
     return 0;
+}
+
+static int ensure_aux_streams(fdn_ctx* h, int n_aux)
+{
+    FDN_DEVICE_WIDE;
+    if (!h->ev_fork) FDN_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < n_aux; i++) {
+        if (!h->aux_stream[i]) FDN_HIP(hipStreamCreateWithFlags(&h->aux_stream[i], hipStreamNonBlocking));
+        if (!h->ev_join[i]) FDN_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+// While a batch runs as sub-batches h->stream points at the stream of the sub-batch being enqueued (every helper launches
+// on h->stream).  Leaving the scope -- normally or through an error return -- puts the handle's stream back, and if the
+// second stream has not been joined (an error on the way) waits for it: nothing of the handle may be freed under it.
+struct SubBatchScope {
+    fdn_ctx* h; hipStream_t main; int n_aux; bool joined = false;
+    SubBatchScope(fdn_ctx* h_, int n_aux_) : h(h_), main(h_->stream), n_aux(n_aux_) {}
+    int fork()
+    {
+        FDN_HIP(hipEventRecord(h->ev_fork, main));
+        for (int i = 0; i < n_aux; i++) FDN_HIP(hipStreamWaitEvent(h->aux_stream[i], h->ev_fork, 0));
+        return 0;
+    }
+    int join()
+    {
+        h->stream = main;
+        h->tn.occ_blocks = 0;
+        for (int i = 0; i < n_aux; i++) {
+            FDN_HIP(hipEventRecord(h->ev_join[i], h->aux_stream[i]));
+            FDN_HIP(hipStreamWaitEvent(main, h->ev_join[i], 0));
+        }
+        joined = true;
+        return 0;
+    }
+    ~SubBatchScope()
+    {
+        h->stream = main;
+        h->tn.occ_blocks = 0;
+        if (n_aux > 0 && !joined) for (int i = 0; i < n_aux; i++) (void)hipStreamSynchronize(h->aux_stream[i]);
+    }
+};
+
+// Sub-batches of a batch of n target slices: 1 or 2.  Automatic (tn.sub_batches == 0): two when some launch of a chain step
+// -- at any pyramid level -- would fill the GPU's workgroup slots fewer than four times over (the tail of a launch is about
+// half a round: under four rounds it is more than a tenth of the launch).  Slots: 4 workgroups per CU for the 3-iteration
+// kernel, 6 for the one-iteration kernel (their LDS footprints at the usual windows).  The 10-round launches of BASELINE
+// configs[2] (10 240 workgroups) stay on one stream.
+static int sweep_sub_batches(const fdn_ctx* h, const fdn_sweep_params* p, const std::vector<PyrLevel>& lv, int path, int n, int H, int W)
+{
+    if (n < 2 || path > 1 || h->tn.sub_batches == 1) return 1;
+    if (h->tn.sub_batches >= 2) return std::min(n, std::min(h->tn.sub_batches, (int)fdn_ctx::MAX_SUB));
+    const int mh = p->winsize / 2;
+    const int bw = path == 0 ? 64 - 6 * mh : 64 - 2 * mh;
+    const long slots = (long)h->tn.cus * (path == 0 ? 4 : 6);
+    // (the finest level decides: it is four fifths of a pyramid's work, and on a grid of many rounds two streams cost more --
+    //  two launches interleaved on every XCD share its L2 -- than the coarse levels' short launches gain: round 6, -l 3 -w 15
+    //  bench volume 1 548 ms on one stream, 1 567 on two)
+    const long blocks = (long)((W + bw - 1) / bw) * n;
+    (void)H; (void)lv;
+    return blocks < 4 * slots ? 2 : 1;
 }
 
 static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H, int W, const double* kernel, int K,
@@ -774,40 +850,73 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
         int n = std::min(C, nr - c0);
         float* acc = out + (size_t)c0 * HW;
         launch_fill(acc, 0.f, (size_t)n * HW, st);
-        for (int side = 0; side < 2; side++) {
-            if (side == 1) launch_axpy_slices(stack, acc, PairBatch{n, r + c0, 0}, H, W, kernel[r], st); // seq:108
-            if (fused) {
-                const float* fin = nullptr;          // seq:94,109: the chain restarts from zero flow
-                float* fout = flow;
-                for (int step = 0; step < r; step++) {
-                    int d = side == 0 ? -(step + 1) : (step + 1); // nearest neighbour first (seq:95,110)
-                    bool keep = p->chained && step + 1 < r;       // the next step is seeded with this flow (seq:98)
-                    if (pyramid) {
-                        if (pyramid_step_fused(h, lv, R, stack, fin, keep ? fout : nullptr, acc, PairBatch{n, r + c0, d}, H, W,
-                                               p->winsize, p->iters, kernel[r + d], wm)) return -1;
-                        if (keep) { fin = fout; fout = fout == flow ? flowB : flow; }
+        if (fused || iter) {
+            // The target slices of a batch are independent (seq:92: one output slice per loop trip): with sub-batches the
+            // batch's targets run as two halves, each the complete chain of both sides on a stream of its own.  A launch
+            // that fills the GPU's workgroup slots only a few times over ends in a tail of idle slots -- 1 280 workgroups
+            // (the 64-slice Z-slab of an 8-GPU rank) are 1.25 rounds of 1 024 slots and cost two; the other half's launches
+            // fill that tail (par's remainder round, src/flowdenoising.py:194-206, exists for the same reason: keep the
+            // workers busy).  Same buffers, same kernels, disjoint slices of every buffer: the bits cannot change.
+            const int G = sweep_sub_batches(h, p, lv, path, n, H, W);
+            h->last_sub_batches = G;
+            if (G > 1 && ensure_aux_streams(h, G - 1)) return -1;
+            SubBatchScope scope(h, G - 1);
+            ScopedTimer span(h, FDN_TIMER_CHAINS);                         // on the main stream: fork ... join
+            if (G > 1) {
+                if (scope.fork()) return -1;                               // R, the pyramid and the zeroed accumulators are ready
+                long blocks = 0;                                           // the occupancy build is chosen for the whole batch's grid
+                if (fused) blocks = (long)((W + (64 - 6 * (p->winsize / 2)) - 1) / (64 - 6 * (p->winsize / 2))) * n;
+                h->tn.occ_blocks = blocks;
+            }
+            size_t pyr_base = 0;
+            for (int g = 0; g < G; g++) {
+                const int off = (int)((long)n * g / G);                    // near-equal contiguous parts (par:181-206 splits its chunks so)
+                const int ng = (int)((long)n * (g + 1) / G) - off;
+                h->stream = g == 0 ? scope.main : h->aux_stream[g - 1];
+                std::vector<PyrLevel> lvg = lv;                            // this sub-batch's own part of the flow pyramid
+                if (pyramid) pyr_base = flow_pyramid_layout(lvg, ng, 2, pyr_base);
+                float* const accg = acc + (size_t)off * HW;
+                float* const fA = flow + (size_t)off * HW * 2;
+                float* const fB = flowB + (size_t)off * HW * 2;
+                const int t0 = r + c0 + off;
+                for (int side = 0; side < 2; side++) {
+                    if (side == 1) launch_axpy_slices(stack, accg, PairBatch{ng, t0, 0}, H, W, kernel[r], h->stream); // seq:108
+                    if (fused) {
+                        const float* fin = nullptr;          // seq:94,109: the chain restarts from zero flow
+                        float* fout = fA;
+                        for (int step = 0; step < r; step++) {
+                            int d = side == 0 ? -(step + 1) : (step + 1); // nearest neighbour first (seq:95,110)
+                            bool keep = p->chained && step + 1 < r;       // the next step is seeded with this flow (seq:98)
+                            if (pyramid) {
+                                if (pyramid_step_fused(h, lvg, R, stack, fin, keep ? fout : nullptr, accg, PairBatch{ng, t0, d}, H, W,
+                                                       p->winsize, p->iters, kernel[r + d], wm)) return -1;
+                                if (keep) { fin = fout; fout = fout == fA ? fB : fA; }
+                                continue;
+                            }
+                            ScopedTimer t(h, FDN_TIMER_FUSED);
+                            launch_farneback_fused(R, stack, fin, keep ? fout : nullptr, accg, PairBatch{ng, t0, d}, H, W,
+                                                   p->winsize, p->iters, kernel[r + d], h->stream, h->tn, 0, 0, wm);     // wm: an integer volume's own accumulate
+                            if (keep) { fin = fout; fout = fout == fA ? fB : fA; }
+                        }
                         continue;
                     }
-                    ScopedTimer t(h, FDN_TIMER_FUSED);
-                    launch_farneback_fused(R, stack, fin, keep ? fout : nullptr, acc, PairBatch{n, r + c0, d}, H, W,
-                                           p->winsize, p->iters, kernel[r + d], st, h->tn, 0, 0, wm);     // wm: an integer volume's own accumulate
-                    if (keep) { fin = fout; fout = fout == flow ? flowB : flow; }
+                    float* const bufs[2] = {fA, fB};
+                    const float* prev = nullptr;         // seq:94,109: the chain restarts from zero flow
+                    for (int step = 0; step < r; step++) {
+                        int d = side == 0 ? -(step + 1) : (step + 1);
+                        bool keep = p->chained && step + 1 < r;
+                        float* res = nullptr;
+                        if (chain_step_iter(h, lvg, R, stack, prev, bufs, accg, PairBatch{ng, t0, d}, H, W, p->winsize, p->iters,
+                                            kernel[r + d], keep, &res, wm)) return -1;
+                        prev = keep ? res : nullptr;
+                    }
                 }
-                continue;
             }
-            if (iter) {
-                float* const bufs[2] = {flow, flowB};
-                const float* prev = nullptr;         // seq:94,109: the chain restarts from zero flow
-                for (int step = 0; step < r; step++) {
-                    int d = side == 0 ? -(step + 1) : (step + 1);
-                    bool keep = p->chained && step + 1 < r;
-                    float* res = nullptr;
-                    if (chain_step_iter(h, lv, R, stack, prev, bufs, acc, PairBatch{n, r + c0, d}, H, W, p->winsize, p->iters,
-                                        kernel[r + d], keep, &res, wm)) return -1;
-                    prev = keep ? res : nullptr;
-                }
-                continue;
-            }
+            if (G > 1 && scope.join()) return -1;
+            continue;
+        }
+        for (int side = 0; side < 2; side++) {
+            if (side == 1) launch_axpy_slices(stack, acc, PairBatch{n, r + c0, 0}, H, W, kernel[r], st); // seq:108
             // per-stage kernels: the flow of every step of the side is kept ([r][n][HW][2]) and the side's warped-
             // Gaussian sweep runs as ONE launch afterwards, the accumulator in a register (12 B per pixel and pair)
             for (int step = 0; step < r; step++) {
@@ -1295,6 +1404,7 @@ FDN_API int fdn_create(int device, fdn_handle* out)
     h->tn.path = env_int("FDN_FORCE_STAGED") ? 1 : env_int("FDN_PATH");
     h->tn.fused_occ = env_int("FDN_FUSED_OCC");
     h->tn.lds_pad = (unsigned)env_int("FDN_LDS_PAD");
+    h->tn.sub_batches = std::min((int)fdn_ctx::MAX_SUB, std::max(0, env_int("FDN_SUB_BATCHES")));
     if (const char* tp = getenv("FDN_LAUNCH_TRACE")) h->trace_fd = open(tp, O_CREAT | O_WRONLY | O_APPEND, 0644);
     *out = h;
     return 0;
@@ -1312,6 +1422,9 @@ FDN_API int fdn_destroy(fdn_handle h)
         if (h->pinned) (void)hipHostFree(h->pinned);
         resolve_stamps(h);
         for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+        for (hipStream_t s : h->aux_stream) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+        if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+        for (hipEvent_t e : h->ev_join) if (e) (void)hipEventDestroy(e);
         if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
         if (h->trace_fd >= 0) close(h->trace_fd);
     }
@@ -1378,7 +1491,23 @@ FDN_API int fdn_set_option(fdn_handle h, const char* name, long value)
     else if (!strcmp(name, "fused_occ")) { if (value && (value < 3 || value > 5) && value != 8) return fail("fused_occ must be 0, 3, 4, 5 or 8"); h->tn.fused_occ = (int)value; }
     else if (!strcmp(name, "lds_pad")) { if (value < 0 || value > 160 * 1024) return fail("lds_pad out of range"); h->tn.lds_pad = (unsigned)value; }
     else if (!strcmp(name, "shard_loopback")) h->tn.shard_loopback = value != 0;
-    else return fail("unknown option '%s' (strict_order, path, fused_occ, lds_pad, shard_loopback)", name);
+    else if (!strcmp(name, "sub_batches")) { if (value < 0 || value > fdn_ctx::MAX_SUB) return fail("sub_batches must be 0 (automatic) or 1 .. %d", (int)fdn_ctx::MAX_SUB); h->tn.sub_batches = (int)value; }
+    else return fail("unknown option '%s' (strict_order, path, fused_occ, lds_pad, shard_loopback, sub_batches)", name);
+    return 0;
+}
+FDN_API int fdn_get_option(fdn_handle h, const char* name, long* value_out)
+{
+    FDN_ENTER(h);
+    if (!name || !value_out) return fail("NULL pointer");
+    if (!strcmp(name, "strict_order")) *value_out = h->tn.strict_order;
+    else if (!strcmp(name, "path")) *value_out = h->tn.path;
+    else if (!strcmp(name, "fused_occ")) *value_out = h->tn.fused_occ;
+    else if (!strcmp(name, "lds_pad")) *value_out = (long)h->tn.lds_pad;
+    else if (!strcmp(name, "shard_loopback")) *value_out = h->tn.shard_loopback;
+    else if (!strcmp(name, "sub_batches")) *value_out = h->tn.sub_batches;
+    else if (!strcmp(name, "last_sub_batches")) *value_out = h->last_sub_batches;     // read-only: what the last sweep ran with
+    else if (!strcmp(name, "compute_units")) *value_out = h->tn.cus;                   // read-only
+    else return fail("unknown option '%s'", name);
     return 0;
 }
 FDN_API int fdn_malloc(fdn_handle h, size_t bytes, void** dptr)

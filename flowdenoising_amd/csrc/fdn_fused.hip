@@ -563,7 +563,7 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
     if (mh == 4) { launch_variant<4, 3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad, wm); return; }
 #endif
     const int BW = 64 - 2 * 2 * 3;
-    const long blocks = (long)((W + BW - 1) / BW) * pb.npairs;
+    const long blocks = tn.occ_blocks > 0 ? tn.occ_blocks : (long)((W + BW - 1) / BW) * pb.npairs;
     switch (choose_occupancy(blocks, tn)) {
     case 3: launch_variant<2, 3>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad, wm); break;
     case 5: launch_variant<2, 5>(Rstack, stack, flow_in, flow_out, acc, pb, H, W, scale, weight, fs, st, tn.lds_pad, wm); break;

@@ -87,6 +87,10 @@ struct Tuning {
     unsigned lds_pad = 0;    // FDN_LDS_PAD: extra dynamic LDS per workgroup (occupancy curves)
     int cus = 256;           // compute units of the handle's device
     int shard_loopback = 0;  // fdn_filter_3d_sharded: the blocks a rank keeps also travel through the transport (send to self)
+    int sub_batches = 0;     // FDN_SUB_BATCHES: 0 = automatic (two when a launch of the pass is under four rounds of workgroup slots),
+                             // 1 = one stream, 2 = the target slices of a batch as two independent sub-batches on two streams
+    long occ_blocks = 0;     // set by the sweep while sub-batches run: the workgroups of BOTH sub-batches' launches, which is
+                             // what the occupancy choice of the 3-iteration kernel goes by (0: the launch's own grid)
 };
 
 // Fused chain step (fdn_fused.hip): for every pair of the batch, the whole level-0 Farneback

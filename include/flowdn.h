@@ -112,7 +112,7 @@ int fdn_workspace_bytes(fdn_handle h, size_t* bytes_out);
 int fdn_mem_info(fdn_handle h, size_t* free_out, size_t* total_out);
 
 /* Switches of a live handle (tests and experiments; fdn_create reads the same from the environment:
- * FDN_STRICT_ORDER, FDN_PATH / FDN_FORCE_STAGED, FDN_FUSED_OCC, FDN_LDS_PAD).  Every path gives the same
+ * FDN_STRICT_ORDER, FDN_PATH / FDN_FORCE_STAGED, FDN_FUSED_OCC, FDN_LDS_PAD, FDN_SUB_BATCHES).  Every path gives the same
  * bits except strict_order:
  *   "strict_order" 0/1  OpenCV's serial f64 running sum along x in FarnebackUpdateFlow_Blur instead of the
  *                       direct window sum (about 20x slower; errors out, never falls back, when a row does
@@ -124,8 +124,15 @@ int fdn_mem_info(fdn_handle h, size_t* free_out, size_t* total_out);
  *   "shard_loopback" 0/1  fdn_filter_3d_sharded: the blocks a rank keeps for itself travel through the transport too
  *                  (a send to self inside the group; the mean through allgather_host even with one rank), so that
  *                  ONE rank on one GPU issues the calls of an N > 1 run
+ *   "sub_batches"  0 automatic, 1 one stream, 2 two: the target slices of a batch are independent (seq:92), so a pass whose
+ *                  launches fill the GPU's workgroup slots only a few times over runs them as two halves, each the whole
+ *                  chain of both sides on a stream of its own -- the tail of one half's launch is filled by the other
+ *                  half's work (the reference's remainder round, par:194-206, keeps its workers busy the same way).
+ *                  Automatic: two when a launch of the pass, at any pyramid level, is under four rounds of slots.
  * No counterpart in the reference (cv2 has no such switches). */
 int fdn_set_option(fdn_handle h, const char* name, long value);
+/* Reads an option back; also the read-only "last_sub_batches" (what the last sweep ran with) and "compute_units". */
+int fdn_get_option(fdn_handle h, const char* name, long* value_out);
 
 /* ---- device memory helpers (so that a host program needs no other HIP binding) ----- */
 int fdn_malloc(fdn_handle h, size_t bytes, void** dptr);
@@ -327,7 +334,10 @@ int fdn_permute_dev(fdn_handle h, const float* d_in, float* d_out, int A, int B,
 #define FDN_TIMER_COLLECTIVE 8       /* multi-GPU exchanges: fdn_filter_3d_sharded times its fdn_comm.exchange calls on the stream
                                         (time waiting for the slowest peer included); a host-level engine adds its own (fdn_add_timer) */
 #define FDN_TIMER_MEAN 9             /* fdn_filter_3d_sharded: the global mean (seq:420) from the ranks' chunk sums                     */
-#define FDN_TIMER_COUNT 10
+#define FDN_TIMER_CHAINS 10         /* a batch's complete chains of both sides as ONE span on the handle's stream, sub-batch fork to join:
+                                        with sub-batches the launches of the two streams overlap and their own times add up to more
+                                        than the wall clock -- this span is what the batch took (bench.py prices the roofline on it) */
+#define FDN_TIMER_COUNT 11
 /* HIP-event timing of the phases above on the handle's stream.  Event pairs are recorded
  * asynchronously (no host sync inside the timed work) and resolved by fdn_get_timers, which
  * returns accumulated milliseconds and the number of timed launches per category. */

@@ -448,11 +448,13 @@ def test_strict_order_refuses_rows_it_cannot_hold(fdn):
 
 
 @pytest.mark.gpu_subprocess
-@pytest.mark.parametrize("env", [{}, {"FDN_FUSED_OCC": "3"}, {"FDN_FUSED_OCC": "4"}, {"FDN_FUSED_OCC": "5"}, {"FDN_FUSED_OCC": "8"}, {"FDN_FORCE_STAGED": "1"}, {"FDN_PATH": "2"}])
+@pytest.mark.parametrize("env", [{}, {"FDN_FUSED_OCC": "3"}, {"FDN_FUSED_OCC": "4"}, {"FDN_FUSED_OCC": "5"}, {"FDN_FUSED_OCC": "8"}, {"FDN_FORCE_STAGED": "1"}, {"FDN_PATH": "2"},
+                                 {"FDN_SUB_BATCHES": "1"}, {"FDN_SUB_BATCHES": "2"}, {"FDN_SUB_BATCHES": "1", "FDN_PATH": "2"}, {"FDN_SUB_BATCHES": "2", "FDN_PATH": "2"}])
 def test_kernel_variants_agree_bit_for_bit(fdn, oracle, tmp_path, env):
     """Every implementation of the chain step (the fused stage-pipelined kernel in its builds for 3, 4
     and 5 workgroups per CU -- different LDS windows and unrolls --, its two-bands-per-workgroup build, the staged per-stage
-    kernels and the one-iteration kernels) must give the oracle's bits on a multi-band image with interior and edge bands."""
+    kernels and the one-iteration kernels; the batch's targets on one stream or as two sub-batches on two) must give the
+    oracle's bits on a multi-band image with interior and edge bands."""
     vol = _vol((10, 70, 300), seed=12)
     np.save(tmp_path / "v.npy", vol)
     code = ("import sys, numpy as np; sys.path.insert(0, %r); import flowdenoising_amd as fd; v = np.load(%r); "
@@ -982,3 +984,48 @@ def test_cli_gpus_refuses_more_ranks_than_slices_and_a_failing_rank_stops_the_jo
     r = subprocess.run(cli + ["-o", str(tmp_path / "no_such_dir" / "o.mrc"), "--gpus", "2"], env=dict(env, FDN_RDV_TIMEOUT="120"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and time.perf_counter() - t0 < 60, r.stderr[-2000:]
+
+
+# ---- the targets of a batch as two sub-batches on two streams (fdn_set_option sub_batches; automatic on small grids) ----------
+@pytest.mark.parametrize("case", [
+    dict(shape=(9, 130, 300), sig=(1.0, None, 1.0), l=0, w=5, border=0),               # 3-iteration kernel; 9 and 300 targets: odd and even halves
+    dict(shape=(8, 90, 200), sig=(1.0, 1.0, 0.5), l=2, w=5, border=1, chained=False),  # ... pyramid (each half its own part of the flow pyramid), wrap, --recompute_flow
+    dict(shape=(9, 130, 300), sig=(1.0, None, 1.0), l=2, w=11, border=1),              # one-iteration kernel with a pyramid, wrapped ends
+    dict(shape=(3, 70, 160), sig=(1.5, 1.0, None), l=1, w=15, border=0),               # three targets: halves of two and one
+    dict(shape=(1, 70, 160), sig=(1.0, None, None), l=0, w=5, border=0),               # one target: nothing to split (last_sub_batches says 1)
+    dict(shape=(10, 48, 56), sig=(1.0, 1.0, 0.5), l=0, w=5, border=0, dtype=np.int16),   # seq on an integer volume (float64 padded volume)
+    dict(shape=(10, 48, 56), sig=(1.0, 0.5, 1.0), l=1, w=15, border=1, dtype=np.uint8),  # par on uint8: fixed-point remap
+    dict(shape=(12, 64, 96), sig=(1.0, 1.0, 1.0), l=1, w=5, border=0, limit=6 << 20),    # a workspace limit: several batches per pass, each split
+])
+def test_sub_batches_on_two_streams_give_the_same_bits(fdn, case):
+    """fdn_set_option("sub_batches", 2): the target slices of a batch run as two independent halves, each the complete chain
+    of both sides on a stream of its own (the tails of small launches are filled by the other half).  Disjoint slices of the
+    same buffers, the same kernels: the same bits as one stream, on both Farneback kernels, with pyramids, both border rules,
+    integer volumes, and under a workspace limit."""
+    from flowdenoising_amd.operators import handle
+    vol = _vol(case["shape"], seed=91)
+    dt = case.get("dtype")
+    if dt is not None:
+        top = 255 if dt is np.uint8 else 3000
+        vol = np.round((vol - vol.min()) * (top / (vol.max() - vol.min())) - (0 if dt is np.uint8 else 700)).astype(dt)
+    ks = [None if s is None else fdn.get_gaussian_kernel(s) for s in case["sig"]]
+    h = handle()
+    outs = {}
+    try:
+        if case.get("limit"):
+            h.set_workspace_limit(case["limit"])
+        for sb in (1, 2, 0):
+            h.set_option("sub_batches", sb)
+            assert h.get_option("sub_batches") == sb
+            outs[sb] = fdn.OF_filter(vol, ks, case["l"], case["w"], border_mode=case["border"], chained=case.get("chained", True))
+            ran = h.get_option("last_sub_batches")
+            n_last = [n for n, s in zip(case["shape"], case["sig"]) if s is not None][-1]
+            if sb == 1 or n_last < 2:
+                assert ran == 1, (sb, ran)
+            elif sb == 2 and not case.get("limit"):        # (under a limit the last batch of the last pass may hold one target)
+                assert ran == 2, (sb, ran)
+    finally:
+        h.set_option("sub_batches", 0)
+        if case.get("limit"):
+            h.set_workspace_limit(0)
+    assert np.array_equal(outs[1], outs[2]) and np.array_equal(outs[1], outs[0])
