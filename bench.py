@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check and the sweep-kernel line")
     ap.add_argument("--no-timers", action="store_true", help="skip per-kernel HIP-event timing")
+    ap.add_argument("--no-sampling", action="store_true", help="do not sample shader clock and socket power during the timed region")
     return ap.parse_args()
 
 
@@ -293,6 +294,88 @@ def cpu_baseline(vol_t, shape, kernel, mean, n_targets, levels, winsize):
                       "for the Z+Y+X job (same pixel-pair count per axis).  A C port: it leaves out what the reference's "
                       "Python adds per pair (the numpy grid build of seq:53-55, 42 ms per 1024x1024 call), so the "
                       "reference itself would be slower than this"}
+
+
+class GpuSampler:
+    """Shader clock and socket power of one GPU while the timed region runs: a side thread reads librocm_smi64 (the library
+    behind `rocm-smi --showclocks --showpower`: sysfs reads, nothing on the GPU's queues) ten times a second.  The fused
+    kernel runs at the clock the socket's power cap leaves it, and boxes differ by 2-3 %: with these fields
+    a slower line can be read as a slower clock or as slower code.  Any failure leaves the fields null with the reason."""
+
+    def __init__(self, pci_id, hz=10.0):
+        import ctypes
+        import threading
+        self.period = 1.0 / hz
+        self.clk, self.pw, self.cap_w, self.error = [], [], None, None
+        self._stop = threading.Event()
+        self._thread = None
+        try:
+            self._lib = lib = ctypes.CDLL("librocm_smi64.so")
+            if lib.rsmi_init(ctypes.c_uint64(0)) != 0:
+                raise OSError("rsmi_init failed")
+            n = ctypes.c_uint32()
+            lib.rsmi_num_monitor_devices(ctypes.byref(n))
+            want = None
+            try:                                        # "0000:05:00.0" -> rocm_smi's BDFID
+                dom, bus, rest = pci_id.split(":")
+                devn, fn = rest.split(".")
+                want = (int(dom, 16) << 32) | (int(bus, 16) << 8) | (int(devn, 16) << 3) | int(fn, 16)
+            except (ValueError, AttributeError):
+                pass
+            self._dv = None
+            for i in range(n.value):
+                b = ctypes.c_uint64()
+                if lib.rsmi_dev_pci_id_get(ctypes.c_uint32(i), ctypes.byref(b)) == 0 and (want is None or (b.value & 0xffffffffffff) == (want & 0xffffffffffff)):
+                    self._dv = i
+                    break
+            if self._dv is None:
+                raise OSError(f"no rocm_smi device with PCI id {pci_id}")
+
+            class Freqs(ctypes.Structure):
+                _fields_ = [("has_deep_sleep", ctypes.c_bool), ("num_supported", ctypes.c_uint32), ("current", ctypes.c_uint32),
+                            ("frequency", ctypes.c_uint64 * 33)]
+            self._Freqs = Freqs
+            cap = ctypes.c_uint64()
+            if lib.rsmi_dev_power_cap_get(ctypes.c_uint32(self._dv), ctypes.c_uint32(0), ctypes.byref(cap)) == 0:
+                self.cap_w = cap.value / 1e6
+            self._thread = threading.Thread(target=self._run, daemon=True)
+        except (OSError, AttributeError) as e:
+            self.error = f"{type(e).__name__}: {e}"
+
+    def _sample(self):
+        import ctypes
+        f = self._Freqs()
+        if self._lib.rsmi_dev_gpu_clk_freq_get(ctypes.c_uint32(self._dv), ctypes.c_int(0), ctypes.byref(f)) == 0 and f.current < 33:
+            self.clk.append(f.frequency[f.current] / 1e6)
+        pw, kind = ctypes.c_uint64(), ctypes.c_int()
+        if self._lib.rsmi_dev_power_get(ctypes.c_uint32(self._dv), ctypes.byref(pw), ctypes.byref(kind)) == 0:
+            self.pw.append(pw.value / 1e6)
+
+    def _run(self):
+        while not self._stop.is_set():
+            self._sample()
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self._thread is not None:
+            self._thread.start()
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+
+    def fields(self):
+        def stat(v):
+            return None if not v else {"mean": round(sum(v) / len(v), 1), "min": round(min(v), 1), "max": round(max(v), 1), "samples": len(v)}
+        c, p = stat(self.clk), stat(self.pw)
+        out = {"gpu_clock_mhz_mean": c and c["mean"], "power_w_mean": p and p["mean"], "power_cap_w": self.cap_w,
+               "gpu_clock_mhz": c, "power_w": p,
+               "sampling": "rank 0's GPU, librocm_smi64 (rsmi_dev_gpu_clk_freq_get SYS / rsmi_dev_power_get) every "
+                           f"{self.period * 1e3:.0f} ms in a side thread over the timed region"}
+        if self.error:
+            out["sampling_error"] = self.error
+        return out
 
 
 def relay_json(line):
@@ -585,8 +668,17 @@ def run(a, job, fallback):
         h.timers(reset=True)
         if eng is not None:
             eng.reset_phase_times()
+    sampler = None
+    if rank == 0 and not a.no_sampling:
+        try:
+            sampler = GpuSampler(_lib.device_pci_id(device))
+        except Exception as e:      # noqa: BLE001 -- the sampler is a side line: it never stops the measurement
+            sampler = None
+            print(f"bench.py: clock / power sampling unavailable: {e}", file=sys.stderr)
     barrier()
     torch.cuda.synchronize()
+    if sampler is not None:
+        sampler.start()
     t0 = time.perf_counter()
     mean = None
     for _ in range(a.steps):
@@ -595,6 +687,8 @@ def run(a, job, fallback):
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if sampler is not None:
+        sampler.stop()
     dt = float(gather_f64([dt]).max())                    # the MAX over ranks
     timers = h.timers() if not a.no_timers else {}
     sub_batches = h.get_option("last_sub_batches")       # what the last pass of the timed steps ran with (automatic on small grids)
@@ -634,6 +728,8 @@ def run(a, job, fallback):
                                          "every flow on unit-range data.  Throughput depends on it a little: larger flows leave the "
                                          "kernel's LDS window more often"},
         }
+        if sampler is not None:
+            res.update(sampler.fields())
         if tr is not None:
             res["transport"] = tr.describe()
         if devices is not None:

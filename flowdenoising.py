@@ -22,18 +22,31 @@ def _warm_gpu(device):
         pass
 
 
+WARM_THREAD_NAME = "fdn-warm-gpu"        # flowdenoising_amd.operators.handle() joins a thread of this name before it makes the first handle
+
+
 def _early_start(argv):
-    if any(a in ("-h", "--help", "--gpus") or a.startswith("--gpus=") for a in argv) or "FDN_RANK" in os.environ or "RANK" in os.environ:
+    # `--gpus` in any spelling argparse accepts (it takes unambiguous prefixes: --g, --gp, --gpu; nothing else begins with --g):
+    # the parent of a multi-GPU run must never open a GPU context
+    def names(a):
+        return a.split("=", 1)[0]
+    if any(a in ("-h", "--help") or (len(names(a)) >= 3 and "--gpus".startswith(names(a))) for a in argv) or "FDN_RANK" in os.environ or "RANK" in os.environ:
         return
     device = 0
     for i, a in enumerate(argv):
-        if a == "--device" and i + 1 < len(argv) and argv[i + 1].isdigit():
-            device = int(argv[i + 1])
-        elif a.startswith("--device=") and a[9:].isdigit():
-            device = int(a[9:])
+        n = names(a)
+        if len(n) >= 3 and "--device".startswith(n):
+            v = a.split("=", 1)[1] if "=" in a else (argv[i + 1] if i + 1 < len(argv) else "")
+            if v.isdigit():
+                device = int(v)
     # this process never imports torch: /opt/rocm's HIP runtime, whichever thread loads the library first (flowdenoising_amd/_lib.py)
     os.environ.setdefault("FDN_SYSTEM_ROCM", "1")
-    threading.Thread(target=_warm_gpu, args=(device,), daemon=True).start()
+    t = threading.Thread(target=_warm_gpu, args=(device,), daemon=True, name=WARM_THREAD_NAME)
+    t.start()
+    # a fast exit -- an option the parser refuses, a missing input file -- must not run the interpreter's and the HIP runtime's
+    # teardown while this thread is still inside the driver's initialisation: atexit handlers run first, and this one waits
+    import atexit
+    atexit.register(t.join, 30.0)
 
 
 if __name__ == "__main__":

@@ -102,9 +102,9 @@ struct fdn_transport {
     // RCCL
     ncclComm_t nccl = nullptr;
     hipStream_t side = nullptr;                // stream of the host all-gather
-    hipEvent_t order = nullptr;                // ... ordered behind the stream the last exchange was enqueued on
-    hipStream_t last = nullptr;                // that stream
-    bool have_last = false;
+    hipEvent_t order = nullptr;                // ... ordered behind the last exchange: recorded on the exchange's stream right after its
+    bool have_order = false;                   // ncclGroupEnd (the stream itself is the caller's and may be gone by the next gather)
+    bool failed = false;                       // the communicator was aborted (a failed init, fdn_transport_abort): destroy waits for nothing
     char* stage = nullptr;                     // device staging of the host all-gather
     size_t stage_cap = 0;
     int count = 0;                             // ranks the communicator itself reports (ncclCommCount; SHM: ranks met at the first barrier)
@@ -208,6 +208,14 @@ int rccl_init(fdn_transport* t, const char* rendezvous)
         if (sh->res != ncclSuccess) return fail("ncclCommInitRank: %s", ncclGetErrorString(sh->res));
         t->nccl = sh->comm;
     }
+    // From here on a communicator exists.  Whatever fails below leaves it ABORTED (ncclCommAbort stops its kernels and makes
+    // the pending operations of the first exchange return), marked `failed`: fdn_transport_destroy then neither waits for the
+    // side stream nor calls ncclCommDestroy on a communicator with work in flight -- either could hang for ever, which is what
+    // the deadlines here exist to prevent.
+    struct AbortOnFailure {
+        fdn_transport* t; bool armed = true;
+        ~AbortOnFailure() { if (armed && t->nccl) { (void)ncclCommAbort(t->nccl); t->nccl = nullptr; t->failed = true; } }
+    } guard{t};
     T_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
     T_HIP(hipEventCreateWithFlags(&t->order, hipEventDisableTiming));
     T_NCCL(ncclCommCount(t->nccl, &t->count));
@@ -236,6 +244,7 @@ int rccl_init(fdn_transport* t, const char* rendezvous)
     char buf[160];
     snprintf(buf, sizeof buf, "rccl %d.%d.%d, rank %d of %d, device %d", ver / 10000, (ver / 100) % 100, ver % 100, t->rank, t->world, t->device);
     t->what = buf;
+    guard.armed = false;
     return 0;
 }
 
@@ -254,7 +263,10 @@ int rccl_exchange(fdn_transport* t, int n, const fdn_msg* msgs, hipStream_t st)
     const ncclResult_t end = ncclGroupEnd();
     if (bad != ncclSuccess) return fail("ncclSend/ncclRecv: %s", ncclGetErrorString(bad));
     if (end != ncclSuccess) return fail("ncclGroupEnd: %s", ncclGetErrorString(end));
-    t->last = st; t->have_last = true;
+    // what a later host all-gather has to wait for: recorded here, on the stream the exchange was enqueued on, while that
+    // stream certainly exists (the caller may destroy it -- close its fdn handle -- before the next gather or barrier)
+    T_HIP(hipEventRecord(t->order, st));
+    t->have_order = true;
     return 0;
 }
 
@@ -273,10 +285,7 @@ int rccl_allgather_host(fdn_transport* t, const void* send, void* recv, size_t b
     }
     char* mine = t->stage;
     char* all = t->stage + slot;
-    if (t->have_last) {
-        T_HIP(hipEventRecord(t->order, t->last));
-        T_HIP(hipStreamWaitEvent(t->side, t->order, 0));
-    }
+    if (t->have_order) T_HIP(hipStreamWaitEvent(t->side, t->order, 0));
     T_HIP(hipMemcpyAsync(mine, send, bytes, hipMemcpyHostToDevice, t->side));
     T_NCCL(ncclAllGather(mine, all, bytes, ncclInt8, t->nccl, t->side));
     T_HIP(hipMemcpyAsync(recv, all, bytes * (size_t)t->world, hipMemcpyDeviceToHost, t->side));
@@ -488,7 +497,7 @@ FDN_API int fdn_transport_create(int kind, int rank, int world, int device, cons
 FDN_API int fdn_transport_destroy(fdn_transport_t t)
 {
     if (!t) return 0;
-    if (t->kind == FDN_TRANSPORT_RCCL) {
+    if (t->kind == FDN_TRANSPORT_RCCL && !t->failed) {
         (void)hipSetDevice(t->device);
         if (t->side) { (void)hipStreamSynchronize(t->side); }
         if (t->nccl) (void)ncclCommDestroy(t->nccl);
@@ -496,6 +505,9 @@ FDN_API int fdn_transport_destroy(fdn_transport_t t)
         if (t->order) (void)hipEventDestroy(t->order);
         if (t->side) (void)hipStreamDestroy(t->side);
     }
+    // (an aborted communicator -- a failed init, fdn_transport_abort: its side stream may still hold operations of peers that
+    //  never answered; waiting for it, freeing device memory (hipFree waits for the device) or ncclCommDestroy could hang.
+    //  The stream, the event and the 512-byte staging block are left to the process's end, which is where such a rank is headed.)
     if (t->kind == FDN_TRANSPORT_SHM) {
         t->out.close_();
         for (auto& m : t->in) m.close_();
@@ -526,7 +538,7 @@ FDN_API int fdn_transport_abort(fdn_transport_t t)
 {
     if (!t) return 0;
     if (t->kind == FDN_TRANSPORT_SHM && t->ctl) t->ctl->failed.store(1);
-    if (t->kind == FDN_TRANSPORT_RCCL && t->nccl) { (void)ncclCommAbort(t->nccl); t->nccl = nullptr; }
+    if (t->kind == FDN_TRANSPORT_RCCL && t->nccl) { (void)ncclCommAbort(t->nccl); t->nccl = nullptr; t->failed = true; }
     return 0;
 }
 

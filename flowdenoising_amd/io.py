@@ -375,12 +375,30 @@ class MappedMrcWriter:
     seq:558-564 is what this replaces (mrcfile.new + set_data: header statistics, float32 data)."""
 
     def __init__(self, path, shape):
+        """The mapping is of a TEMPORARY file next to `path` (same directory: same file system, so the final rename is atomic
+        and the page cache pages stay the ones the GPU wrote): the reference writes its output only after the last pass
+        (seq:558-564), so a run that fails on the way must leave an existing output file as it was -- finish() renames
+        the temporary file over `path`, close() without finish() removes it."""
         import mmap
+        import tempfile
         self.shape = tuple(int(v) for v in shape)
         self.nbytes = 1024 + 4 * int(np.prod(self.shape))
-        self.f = open(path, "w+b")
-        self.f.truncate(self.nbytes)
-        self.mm = mmap.mmap(self.f.fileno(), self.nbytes)
+        self.path = str(path)
+        d, base = os.path.split(os.path.abspath(self.path))
+        fd, self.tmp_path = tempfile.mkstemp(prefix="." + base + ".", suffix=".part", dir=d)
+        self.f = os.fdopen(fd, "w+b")
+        try:
+            # (mkstemp creates mode 0600; an output file is an ordinary one: what open(path, "wb") would have given it)
+            umask = os.umask(0)
+            os.umask(umask)
+            os.chmod(self.tmp_path, 0o666 & ~umask)
+            self.f.truncate(self.nbytes)
+            self.mm = mmap.mmap(self.f.fileno(), self.nbytes)
+        except BaseException:
+            self.f.close()
+            os.unlink(self.tmp_path)
+            raise
+        self.finished = False
         self.data = np.frombuffer(self.mm, dtype="<f4", count=int(np.prod(self.shape)), offset=1024).reshape(self.shape)
         self.whole = np.frombuffer(self.mm, dtype=np.uint8)
         self.pinned_by = None
@@ -400,6 +418,7 @@ class MappedMrcWriter:
 
     def finish(self, stats):
         self.mm[0:1024] = bytes(_mrc_header(self.shape, stats))
+        self.finished = True
         self.close()
 
     def close(self):
@@ -414,6 +433,13 @@ class MappedMrcWriter:
                 pass
             self.mm = None
             self.f.close()
+            if self.finished:
+                os.replace(self.tmp_path, self.path)     # the output file appears complete, or not at all
+            else:
+                try:
+                    os.unlink(self.tmp_path)
+                except OSError:
+                    pass
 
 
 # ---------------------------------------------------------------------------- dispatch (CLI rules)

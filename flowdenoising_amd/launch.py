@@ -34,11 +34,15 @@ def _rendezvous_root():
     return tempfile.gettempdir()
 
 
-def spawn(argv, world, env=None, relay=None, errors=None):
+def spawn(argv, world, env=None, relay=None, errors=None, deadline=None):
     """Run `argv` (a full command line, e.g. [sys.executable, script, ...]) as `world` rank processes and wait for them.
     relay: a function called with every stdout line of rank 0 (default: print it); the other ranks' stdout is dropped,
-    stderr goes straight through.  A rank that fails takes the others down (they would wait for it otherwise).
+    stderr goes straight through.  A rank that fails takes the others down (they would wait for it otherwise) -- and so
+    does a rank that has left error.<rank> in the rendezvous directory but cannot leave (report_failure), and the passing
+    of `deadline` seconds (FDN_NATIVE_DEADLINE; default: none for the CLI, whose jobs are as long as their volumes).
     errors: a list that receives what failed ranks left behind with report_failure()."""
+    if deadline is None and os.environ.get("FDN_NATIVE_DEADLINE"):
+        deadline = float(os.environ["FDN_NATIVE_DEADLINE"])
     rdv = tempfile.mkdtemp(prefix="fdn_rdv_", dir=_rendezvous_root())      # mode 0700, ours alone
     base = dict(os.environ if env is None else env)
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this host driver
@@ -62,6 +66,8 @@ def spawn(argv, world, env=None, relay=None, errors=None):
         reader.start()
         code = 0
         pending = list(procs)
+        t0 = time.monotonic()
+        told = False
         while pending:
             for p in list(pending):
                 try:
@@ -73,6 +79,22 @@ def spawn(argv, world, env=None, relay=None, errors=None):
                     code = rc
                     for q in pending:              # a failed rank takes the others down -- the exact processes started above
                         q.terminate()
+            # a rank that reported a failure but is stuck on its way out (a thread inside RCCL), or an overdue job
+            overdue = deadline is not None and time.monotonic() - t0 > deadline
+            if pending and not told and (overdue or failure_reports(rdv)):
+                told = True
+                if overdue:
+                    report_failure(rdv, "parent", f"the job did not finish within {deadline:.0f} s")
+                if code == 0:
+                    code = 1
+                grace = time.monotonic() + 10
+                for q in pending:
+                    q.terminate()
+                while any(q.poll() is None for q in pending) and time.monotonic() < grace:
+                    time.sleep(0.05)
+                for q in pending:
+                    if q.poll() is None:
+                        q.kill()
         reader.join(timeout=10)
         if errors is not None:
             errors.extend(failure_reports(rdv))
@@ -122,9 +144,13 @@ def supervise_rank(argv, job, relay=None, deadline=None):
     the whole job.  So each rank -- before it has touched a GPU -- runs the native job's rank in ONE child process of its
     own (FDN_RANK / FDN_WORLD / FDN_RDV as spawn() would set them) and watches it.  A native rank that fails leaves
     error.<rank> in the shared rendezvous directory; every supervisor that sees one ends its own child (the exact process
-    it started) -- as it does when `deadline` seconds pass (FDN_NATIVE_DEADLINE, default 900).  Returns (exit code, reasons):
-    0 = the native job ran to its end; otherwise the caller is a process that has never initialised the GPU and may run
-    another engine in itself."""
+    it started) -- as it does when `deadline` seconds pass (FDN_NATIVE_DEADLINE, default 900).
+    The supervisors then AGREE before any of them returns: each leaves done.<rank> ("ok" or "failed") once its child has
+    gone, waits until every rank's is there, and all of them return the same verdict -- 0 only if every child ended well and
+    nobody left an error.<rank> (a child writes its report before it exits, so the reports are complete by then).  Rank 0's
+    stdout is held back until that verdict and dropped if it is a failure: a job never prints a result line and then another
+    one from the fallback engine.  Returns (exit code, reasons): 0 = the native job ran to its end on every rank; otherwise
+    the caller is a process that has never initialised the GPU and may run another engine in itself -- as all its peers do."""
     rank, world, local, rdv = job
     if deadline is None:
         deadline = float(os.environ.get("FDN_NATIVE_DEADLINE", "900"))
@@ -134,14 +160,11 @@ def supervise_rank(argv, job, relay=None, deadline=None):
         env.pop(k, None)
     child = subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=(rank == 0))
     reader = None
+    held = []                                     # rank 0's stdout, until the supervisors have agreed
     if rank == 0:
         def pump():
             for line in child.stdout:
-                if relay is not None:
-                    relay(line)
-                else:
-                    sys.stdout.write(line)
-                    sys.stdout.flush()
+                held.append(line)
         reader = threading.Thread(target=pump, daemon=True)
         reader.start()
     t0 = time.monotonic()
@@ -169,7 +192,57 @@ def supervise_rank(argv, job, relay=None, deadline=None):
             child.kill()
     if reader is not None:
         reader.join(timeout=10)
-    return rc, failure_reports(rdv)
+    # the agreement: every supervisor's done.<rank>, then one verdict for all
+    _leave_note(rdv, f"done.{rank}", "ok" if rc == 0 else "failed")
+    limit = time.monotonic() + max(30.0, deadline - (time.monotonic() - t0) + 30.0)
+    verdicts = None
+    while verdicts is None and time.monotonic() < limit:
+        verdicts = _read_notes(rdv, "done.", world)
+        if verdicts is None:
+            time.sleep(0.05)
+    reasons = failure_reports(rdv)
+    if verdicts is None:
+        reasons = reasons + [f"rank {rank}: not every rank's supervisor reported within the deadline"]
+    ok = verdicts is not None and all(v == "ok" for v in verdicts) and not reasons
+    _leave_note(rdv, f"ack.{rank}", "1")          # (rank 0 removes the directory: not before everybody has read it)
+    if rank == 0:
+        until = time.monotonic() + 10.0
+        while _read_notes(rdv, "ack.", world) is None and time.monotonic() < until:
+            time.sleep(0.05)
+        if ok:
+            for line in held:
+                if relay is not None:
+                    relay(line)
+                else:
+                    sys.stdout.write(line)
+                    sys.stdout.flush()
+        elif held:
+            sys.stderr.write("flowdenoising_amd.launch: the native job's output is dropped: not every rank ended well\n")
+    if ok:
+        return 0, []
+    return (rc or 1), (reasons or [f"rank {rank}: another rank's native process failed"])
+
+
+def _leave_note(rdv, name, text):
+    try:
+        tmp = os.path.join(rdv, "." + name + ".tmp")
+        with open(tmp, "w") as f:
+            f.write(text)
+        os.replace(tmp, os.path.join(rdv, name))
+    except OSError:
+        pass
+
+
+def _read_notes(rdv, prefix, world):
+    """The `world` notes <prefix><rank> in rank order, or None while one is missing."""
+    out = []
+    for r in range(world):
+        try:
+            with open(os.path.join(rdv, f"{prefix}{r}")) as f:
+                out.append(f.read().strip())
+        except OSError:
+            return None
+    return out
 
 
 def _proc_start_time(pid):
@@ -209,14 +282,24 @@ def job():
         tag = "".join(c if c.isalnum() else "-" for c in os.environ.get("TORCHELASTIC_RUN_ID", ""))[:24]
         name = (f"fdn_rdv_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}_{ppid}_{_proc_start_time(ppid)}"
                 f"_{tag}_{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}")
-        rdv = os.environ.get("FDN_RDV") or os.path.join(_rendezvous_root(), name)
+        # FDN_RDV names a directory of the user's choice: the job still gets a subdirectory of its own there, so that what an
+        # earlier job left behind (error.*, dev.*, done.*) is never read as this job's
+        base = os.environ.get("FDN_RDV")
+        if base:
+            _private_dir(base)
+        rdv = os.path.join(base or _rendezvous_root(), name)
+        _derived.add(rdv)
         return r, w, int(os.environ.get("LOCAL_RANK", r)), _private_dir(rdv)
     return None
 
 
+_derived = set()
+
+
 def remove_derived_rendezvous(rdv):
-    """A directory job() derived under torch.distributed.run is ours to remove (spawn() removes its own)."""
-    if "FDN_RDV" not in os.environ:
+    """A directory job() derived under torch.distributed.run is ours to remove (spawn() removes its own; a rank process that
+    was handed its directory through FDN_RDV leaves it to whoever made it)."""
+    if rdv in _derived:
         shutil.rmtree(rdv, ignore_errors=True)
 
 
@@ -242,7 +325,17 @@ def make_transport(rank, world, local_rank, rdv, kind=None):
             ids = _exchange_lines(sub, rank, world, _lib.device_pci_id(device))
             if len(set(ids)) == world:
                 kind = "rccl"
-    return _lib.Transport(kind, rank, world, device, sub), device
+    try:
+        return _lib.Transport(kind, rank, world, device, sub), device
+    except _lib.FlowdnError as e:
+        # The transport could not be created.  After an RCCL initialisation that ran into its deadline a helper thread is
+        # still inside ncclCommInitRank (include/flowdn_rccl.h): the interpreter's orderly teardown -- atexit handlers, the
+        # HIP runtime's own -- could wait for it for ever.  Say why, for the other ranks' supervisors, and leave at once.
+        report_failure(rdv, rank, f"{type(e).__name__}: {e}")
+        sys.stderr.write(f"flowdenoising_amd.launch: rank {rank}: {e}\n")
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(1)
 
 
 def _exchange_lines(sub, rank, world, line, timeout=None):

@@ -38,6 +38,11 @@ def handle(device=0):
     with _handles_lock:
         h = _handles.get(device)
         if h is None:
+            # the command-line script opens the GPU context in a thread of its own while the package is being imported
+            # (flowdenoising.py: a handle created and destroyed there); the first real handle waits for that thread
+            for t in threading.enumerate():
+                if t.name == "fdn-warm-gpu" and t is not threading.current_thread():
+                    t.join(30.0)
             h = _handles[device] = _lib.Handle(device)
         return h
 
@@ -222,33 +227,37 @@ def filter_3d_own_mean(vol, kernel, params, device=0, stats=None, float32_semant
             # an integer volume's mean is numpy's float64 one (params.pad64); Farneback sees it as float32
             mean = np.float32(params.pad64) if params.warp_mode == _lib.WARP_F64_PADDED else h.mean_dev(d_in, src.size)
             h.filter_3d_dev(d_in, d_out, src.shape, kernel, mean, params)
-            if mapped_out is not None and not tiff_downcast:
-                # The passes are ENQUEUED now (nothing above waits for them) and run for a while on their own: the output
-                # file is mapped and its pages faulted in and page-locked meanwhile.  (Not earlier: hipHostRegister holds a
-                # runtime lock that kernel launches wait for -- started before the launches it added its 0.3 s to the passes.)
-                import threading
-                try:
-                    writer = mapped_out()
-                    hw = _lib.Handle(device)          # page-locking goes through a handle of its own
-                    ready = {}
-                    prep = threading.Thread(target=lambda: ready.setdefault("pinned", writer.prepare(hw)), daemon=True)
-                    prep.start()
-                except OSError:
-                    writer = prep = None
-            if prep is not None:
-                prep.join()                           # (before the statistics' launches: they would queue behind the page-locking)
-            if stats is not None or tiff_downcast or writer is not None:
-                st_out = h.stats_volume(d_out, src.shape)
-                if stats is not None:
-                    stats["out"] = st_out
-            d_res = d_out
-            if tiff_downcast:
-                out = np.empty(src.shape, dtype=np.uint8 if st_out["max"] < 256 else np.uint16)
-                h.truncate_dev(d_out, out.dtype, d_in, src.size)      # the input's device copy is no longer needed
-                d_res = d_in
-            lap("compute")
-            if writer is not None:
-                try:
+            try:
+                if mapped_out is not None and not tiff_downcast:
+                    # The passes are ENQUEUED now (nothing above waits for them) and run for a while on their own: the output
+                    # file is mapped and its pages faulted in and page-locked meanwhile.  (Not earlier: hipHostRegister holds a
+                    # runtime lock that kernel launches wait for -- started before the launches it added its 0.3 s to the passes.)
+                    import threading
+                    try:
+                        writer = mapped_out()
+                        hw = _lib.Handle(device)          # page-locking goes through a handle of its own
+                        ready = {}
+                        prep = threading.Thread(target=lambda: ready.setdefault("pinned", writer.prepare(hw)), daemon=True)
+                        prep.start()
+                    except (OSError, _lib.FlowdnError):   # no mapping here, or no second handle: the slab writer below
+                        if writer is not None:
+                            writer.close()
+                        if hw is not None:
+                            hw.close()
+                        writer = prep = hw = None
+                if prep is not None:
+                    prep.join()                           # (before the statistics' launches: they would queue behind the page-locking)
+                if stats is not None or tiff_downcast or writer is not None:
+                    st_out = h.stats_volume(d_out, src.shape)
+                    if stats is not None:
+                        stats["out"] = st_out
+                d_res = d_out
+                if tiff_downcast:
+                    out = np.empty(src.shape, dtype=np.uint8 if st_out["max"] < 256 else np.uint16)
+                    h.truncate_dev(d_out, out.dtype, d_in, src.size)      # the input's device copy is no longer needed
+                    d_res = d_in
+                lap("compute")
+                if writer is not None:
                     if timing is not None:
                         timing["out_pinned"] = bool(ready.get("pinned"))
                     if ready.get("pinned"):
@@ -258,14 +267,21 @@ def filter_3d_own_mean(vol, kernel, params, device=0, stats=None, float32_semant
                         step = max(1, (128 << 20) // max(per, 1))
                         for z0 in range(0, src.shape[0], step):
                             h.d2h(writer.data[z0:z0 + step], d_res + z0 * per)
-                    writer.finish(st_out)
+                    writer.finish(st_out)                     # renames the finished file over the output path
                     if stats is not None:
                         stats["streamed"] = True
-                finally:
+                    lap("d2h")
+                    return None
+            finally:
+                # whatever happened between the writer's creation and here -- a failed pass, a failed reduction, an interrupt --
+                # the page-locking thread has ended, the mapping is closed (an unfinished temporary file removed: the output
+                # path is untouched, as with the reference, which writes after its last pass) and the extra handle is gone
+                if prep is not None and prep.is_alive():
+                    prep.join()
+                if writer is not None:
                     writer.close()
+                if hw is not None:
                     hw.close()
-                lap("d2h")
-                return None
             pin_out = big and h.host_register(out)
             try:
                 if sink is None:

@@ -60,9 +60,14 @@ int fdn_transport_count(fdn_transport_t t, int* out);
 /* The PCI bus id of this rank's device (hipDeviceGetPCIBusId, e.g. "0000:05:00.0"; "host" for device -1): all-gathered,
  * N distinct strings show N distinct GPUs -- a run whose ranks share devices is a rehearsal and says so. */
 int fdn_transport_device_id(fdn_transport_t t, char* buf, int cap);
-/* A rank that cannot go on (a reader or writer failed, an exception above the ABI) tells the others before it leaves, so
- * that they stop waiting: SHM sets the job's failed flag, RCCL aborts the communicator (ncclCommAbort).  The transport
- * can only be destroyed afterwards. */
+/* A rank that cannot go on (a reader or writer failed, an exception above the ABI) gives its transport up before it leaves.
+ * SHM sets the job's failed flag: the other ranks see it in their next wait and return an error.  RCCL: ncclCommAbort --
+ * which is LOCAL: it stops this rank's own pending operations so that its teardown cannot hang; peers blocked in an
+ * exchange with this rank are not woken by it (RCCL has no timeout after initialisation).  They are ended by whoever
+ * supervises the job: the rank leaves error.<rank> in the rendezvous directory (launch.report_failure) and the parent
+ * (launch.spawn) or the per-rank supervisors (launch.supervise_rank) terminate the remaining rank processes.
+ * Afterwards the transport can only be destroyed; fdn_transport_destroy then waits for nothing (the aborted communicator's
+ * stream may hold operations that never complete). */
 int fdn_transport_abort(fdn_transport_t t);
 
 /* The communicator to hand to fdn_filter_3d_sharded (valid until fdn_transport_destroy). */

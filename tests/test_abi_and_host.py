@@ -379,6 +379,19 @@ def test_mapped_mrc_writer_writes_the_file_write_mrc_writes(tmp_path):
         w.close()                                   # a second close is harmless
         assert open(tmp_path / name, "rb").read() == want
         assert getattr(h, "live", 0) == 0
+    # a run that fails before finish() leaves an existing output file as it was (the reference writes after its last pass,
+    # seq:558-564) and no temporary file behind; until finish() the output path is not touched at all
+    before = sorted(os.listdir(tmp_path))
+    w = fio.MappedMrcWriter(str(tmp_path / "a.mrc"), v.shape)
+    w.prepare(NoPin())
+    w.data[...] = 0
+    assert open(tmp_path / "a.mrc", "rb").read() == want
+    w.close()
+    assert open(tmp_path / "a.mrc", "rb").read() == want and sorted(os.listdir(tmp_path)) == before
+    w = fio.MappedMrcWriter(str(tmp_path / "new.mrc"), v.shape)
+    w.close()
+    assert not os.path.exists(tmp_path / "new.mrc") and sorted(os.listdir(tmp_path)) == before
+    assert (os.stat(tmp_path / "a.mrc").st_mode & 0o777) == (os.stat(tmp_path / "ref.mrc").st_mode & 0o777)
 
 
 def test_gpu_tests_that_start_processes_are_marked():

@@ -191,3 +191,43 @@ def test_a_failed_native_rank_ends_every_supervised_rank_with_the_reason(fdn, tm
     recs = [json.loads(out.strip().splitlines()[-1]) for _, out in res]
     assert all(r["rc"] != 0 for r in recs)
     assert all(any("no links today" in w for w in r["why"]) for r in recs), recs
+
+
+def test_supervisors_agree_when_a_rank_fails_after_another_has_finished(fdn, tmp_path):
+    """Rank 0's native child prints its result and exits 0 at once; rank 1's fails a second later (in its teardown, say).
+    The supervisors agree before either returns (done.<rank> notes): BOTH report the failure -- so both go on to the same
+    fallback together instead of one waiting for peers that are gone -- and rank 0's already printed line is dropped, so
+    the job cannot emit a native result and then a second line from the fallback."""
+    import json
+    child = ("import os, sys, time; sys.path.insert(0, %r)\n"
+             "from flowdenoising_amd import launch\n"
+             "r, w, l, rdv = launch.job()\n"
+             "if r == 0:\n"
+             "    print('{\"value\": 1}'); sys.exit(0)\n"
+             "time.sleep(1.0)\n"
+             "launch.report_failure(rdv, r, 'RuntimeError: teardown failed'); sys.exit(3)\n") % ROOT
+    res = _supervised(tmp_path, child, port=29878)
+    recs = [json.loads(out.strip().splitlines()[-1]) for _, out in res]
+    assert all(r["rc"] != 0 for r in recs), recs
+    assert all(any("teardown failed" in w for w in r["why"]) for r in recs), recs
+    assert "child:" not in res[0][1]
+
+
+def test_a_user_supplied_rendezvous_directory_gets_a_subdirectory_per_job(fdn, tmp_path):
+    """FDN_RDV under a torchrun-like parent names a directory of the user's choice; stale error.* files of an earlier job in
+    it must not end this job's children at once: the job works in a subdirectory of its own."""
+    import json
+    (tmp_path / "rdv").mkdir()
+    (tmp_path / "rdv" / "error.1").write_text("stale: from an earlier run")
+    child = ("import os, sys; sys.path.insert(0, %r)\n"
+             "from flowdenoising_amd import _lib, launch\n"
+             "r, w, l, rdv = launch.job()\n"
+             "t = _lib.Transport('shm', r, w, -1, rdv)\n"
+             "t.barrier(); t.close()\n"
+             "print('rank', r, 'ok')\n") % ROOT
+    res = _supervised(tmp_path, child, extra_env={"FDN_RDV": str(tmp_path / "rdv")}, port=29879)
+    recs = [json.loads(out.strip().splitlines()[-1]) for _, out in res]
+    assert [r["rc"] for r in recs] == [0, 0], recs
+    assert "child: rank 0 ok" in res[0][1]
+    assert (tmp_path / "rdv" / "error.1").exists()                 # the user's directory itself is left alone ...
+    assert [n for n in os.listdir(tmp_path / "rdv") if n.startswith("fdn_rdv_")] == []   # ... and the job's own part is gone
