@@ -29,6 +29,8 @@ def pytest_collection_modifyitems(config, items):
     mode's worker threads, rank threads, rank processes -- and never in a short session or one without them; what the runtime
     objects to is not known (profiles/history/NOTES_r05.md, section 5).  The long-lived test process now only ever does
     single-threaded GPU work, and all of it before the first other GPU process starts."""
+    if os.environ.get("FDN_TEST_INPROCESS") == "1":      # diagnostic sessions (run_in_fresh_process below): round 5's original order
+        return
     tail = [it for it in items if _starts_gpu_processes(it)]
     if tail:
         ids = {id(it) for it in tail}
@@ -59,6 +61,28 @@ def run_in_fresh_process(code, arrays, tmp_path, timeout=600, env=None):
     (profiles/history/NOTES_r05.md, section 5); the long-lived test process therefore stays single-threaded on the GPU."""
     import subprocess
     import numpy as np
+    if os.environ.get("FDN_TEST_INPROCESS") == "1":
+        # Diagnostic only (never the default): run the code in THIS process and keep collection order -- the configuration in
+        # which round 5's sessions aborted -- to get the runtime's own message: `--capture=sys` leaves fd 2 to the runtime
+        # (AMD_LOG_LEVEL), tools/abort_trace.c the native call chain.
+        import contextlib
+        import io
+        scope = {k: np.asarray(v) for k, v in arrays.items()}
+        scope["np"] = np
+        scope["out"] = {}
+        for p in (ROOT, os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        buf = io.StringIO()
+        old = dict(os.environ)
+        os.environ.update(env or {})
+        try:
+            with contextlib.redirect_stdout(buf):
+                exec(compile(code, "<run_in_fresh_process>", "exec"), scope)
+        finally:
+            os.environ.clear()
+            os.environ.update(old)
+        return {k: np.asarray(v) for k, v in scope["out"].items()}, buf.getvalue()
     np.savez(tmp_path / "fresh_in.npz", **{k: np.asarray(v) for k, v in arrays.items()})
     script = ("import sys, numpy as np\nsys.path.insert(0, %r)\nsys.path.insert(0, %r)\n"
               "_in = np.load(%r, allow_pickle=False)\n"
