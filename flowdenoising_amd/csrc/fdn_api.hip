@@ -182,6 +182,7 @@ struct fdn_ctx {
     DevBuf R, M0, M1, flow, stack, sweep_out, vol_a, vol_b, partials, pair, vol_in, vol_out;
     void* pinned = nullptr;          // host staging of the pair-level entry points (hipHostMalloc)
     size_t pinned_cap = 0;
+    void* bounce = nullptr;          // page-locked bounce buffer of copy_host / copy_host_2d (hipHostMalloc, BOUNCE_BYTES)
     DevBuf Rpyr, flow_pyr, pyr_tmp, area_tab;   // pyramid levels >= 1
     DevBuf sh_send, sh_recv, sh_stack, sh_out[2], sh_tmp;   // fdn_filter_3d_sharded: staging, stack and pass outputs
     struct AreaKey { int sh, sw, dh, dw; } area_key = {0, 0, 0, 0};
@@ -277,6 +278,114 @@ static int ensure_pinned(fdn_ctx* h, size_t bytes)
     hipError_t e = hipHostMalloc(&h->pinned, bytes, hipHostMallocDefault);
     if (e != hipSuccess) { h->pinned = nullptr; return fail("hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
     h->pinned_cap = bytes;
+    return 0;
+}
+
+// ---- copies between CALLER-OWNED host memory and the device -----------------------------------------------------------
+// The library never hands pageable host memory of its callers (or of its own short-lived std::vectors) to the copy engines.
+// For such a copy above about 1 MB the HIP runtime page-locks the pages ON THE FLY (hsa_amd_memory_lock_to_pool on the
+// page-rounded range, the engine then reads or writes the user's memory directly) and keeps that registration after the
+// call; it is not told when the application frees or trims that memory (numpy arrays, the heap's top, thread arenas), and a
+// later copy that meets a registration whose pages are gone ends in "Memory access fault by GPU ... Reason: Unknown" and an
+// abort of the process -- the abort that ended 6 of 19 long test sessions in round 5 and was caught with this message in
+// round 6, in a plain 1.09 MB fdn_memcpy_d2h (profiles/history/NOTES_r06.md, section 2).  So a copy here is one of three things:
+//   * the memory is page-locked already (hipHostRegister by the caller -- the CLI, the out-of-core mode --, hipHostMalloc):
+//     one DMA, as before;
+//   * 8 MB and more: page-locked by the library for the duration of the call (hipHostRegister / hipHostUnregister: an
+//     explicit registration is removed when the call returns; 20 ms per 2 GiB), one DMA at PCIe speed;
+//   * otherwise, or when the registration is refused: through the handle's own page-locked bounce buffer in pieces of 4 MB
+//     (one host memcpy more: 0.1 ms per MB).
+// All of them are complete when the function returns (the callers of these entry points wait anyway).
+static constexpr size_t BOUNCE_BYTES = (size_t)4 << 20;
+
+static bool host_is_locked(const void* p, size_t bytes)
+{
+    if (!bytes) return true;
+    hipPointerAttribute_t a;
+    for (const char* q : {(const char*)p, (const char*)p + bytes - 1}) {
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+
+static int ensure_bounce(fdn_ctx* h)
+{
+    if (h->bounce) return 0;
+    FDN_DEVICE_WIDE;
+    hipError_t e = hipHostMalloc(&h->bounce, BOUNCE_BYTES, hipHostMallocDefault);
+    if (e != hipSuccess) { h->bounce = nullptr; return fail("hipHostMalloc(%zu bytes) failed: %s", BOUNCE_BYTES, hipGetErrorString(e)); }
+    return 0;
+}
+
+// host <-> device, contiguous; returns after the copy has completed
+static int copy_host(fdn_ctx* h, void* dst, const void* src, size_t bytes, bool to_device)
+{
+    if (!bytes) return 0;
+    hipStream_t st = h->stream;
+    void* host = to_device ? const_cast<void*>(src) : dst;
+    const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+    bool locked_here = false;
+    if (!host_is_locked(host, bytes) && bytes >= ((size_t)8 << 20)) {
+        if (hipHostRegister(host, bytes, hipHostRegisterDefault) == hipSuccess) locked_here = true;
+        else (void)hipGetLastError();          // refused (a read-only mapping, the locked-memory limit): the bounce buffer below
+    }
+    if (locked_here || host_is_locked(host, bytes)) {
+        hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (locked_here) (void)hipHostUnregister(host);
+        if (e != hipSuccess) return fail("hipMemcpyAsync (%zu bytes, %s): %s", bytes, to_device ? "host to device" : "device to host", hipGetErrorString(e));
+        return 0;
+    }
+    if (ensure_bounce(h)) return -1;
+    for (size_t off = 0; off < bytes; off += BOUNCE_BYTES) {
+        const size_t n = std::min(BOUNCE_BYTES, bytes - off);
+        if (to_device) {
+            memcpy(h->bounce, (const char*)src + off, n);
+            FDN_HIP(hipMemcpyAsync((char*)dst + off, h->bounce, n, hipMemcpyHostToDevice, st));
+            FDN_HIP(hipStreamSynchronize(st));          // the buffer is refilled next
+        } else {
+            FDN_HIP(hipMemcpyAsync(h->bounce, (const char*)src + off, n, hipMemcpyDeviceToHost, st));
+            FDN_HIP(hipStreamSynchronize(st));
+            memcpy((char*)dst + off, h->bounce, n);
+        }
+    }
+    return 0;
+}
+
+// the strided form: `height` rows of `width` bytes; the host side's pitch is hpitch, the device side's dpitch
+static int copy_host_2d(fdn_ctx* h, void* dev, size_t dpitch, void* host, size_t hpitch, size_t width, size_t height, bool to_device)
+{
+    if (!width || !height) return 0;
+    hipStream_t st = h->stream;
+    const size_t span = (height - 1) * hpitch + width;
+    if (host_is_locked(host, span)) {
+        if (to_device) FDN_HIP(hipMemcpy2DAsync(dev, dpitch, host, hpitch, width, height, hipMemcpyHostToDevice, st));
+        else FDN_HIP(hipMemcpy2DAsync(host, hpitch, dev, dpitch, width, height, hipMemcpyDeviceToHost, st));
+        FDN_HIP(hipStreamSynchronize(st));
+        return 0;
+    }
+    if (ensure_bounce(h)) return -1;
+    if (width > BOUNCE_BYTES) {                 // rows longer than the buffer: row by row, each as a contiguous copy
+        for (size_t r = 0; r < height; r++) {
+            if (to_device ? copy_host(h, (char*)dev + r * dpitch, (const char*)host + r * hpitch, width, true)
+                          : copy_host(h, (char*)host + r * hpitch, (const char*)dev + r * dpitch, width, false)) return -1;
+        }
+        return 0;
+    }
+    const size_t rows = std::max<size_t>(1, BOUNCE_BYTES / width);      // rows per piece, packed in the buffer
+    for (size_t r0 = 0; r0 < height; r0 += rows) {
+        const size_t nr = std::min(rows, height - r0);
+        if (to_device) {
+            for (size_t r = 0; r < nr; r++) memcpy((char*)h->bounce + r * width, (const char*)host + (r0 + r) * hpitch, width);
+            FDN_HIP(hipMemcpy2DAsync((char*)dev + r0 * dpitch, dpitch, h->bounce, width, width, nr, hipMemcpyHostToDevice, st));
+            FDN_HIP(hipStreamSynchronize(st));
+        } else {
+            FDN_HIP(hipMemcpy2DAsync(h->bounce, width, (const char*)dev + r0 * dpitch, dpitch, width, nr, hipMemcpyDeviceToHost, st));
+            FDN_HIP(hipStreamSynchronize(st));
+            for (size_t r = 0; r < nr; r++) memcpy((char*)host + (r0 + r) * hpitch, (const char*)h->bounce + r * width, width);
+        }
+    }
     return 0;
 }
 
@@ -441,7 +550,7 @@ static int ensure_area_tables(fdn_ctx* h, int sh, int sw, int dh, int dw)
     char* d = (char*)h->area_tab.p;
     auto put = [&](const void* src, size_t cnt) -> const void* {
         const void* at = d;
-        (void)hipMemcpy(d, src, cnt * 4, hipMemcpyHostToDevice);
+        (void)copy_host(h, d, src, cnt * 4, true);
         d += cnt * 4;
         return at;
     };
@@ -1277,8 +1386,7 @@ static int shard_mean(fdn_ctx* h, const ShardPlan& pl, const fdn_comm* comm, con
         size_t m = 0;
         for (int k = 0; k < world; k++) m = std::max(m, starts[k + 1] - starts[k]);
         std::vector<float> mine(m, 0.f), all(m * world);
-        FDN_HIP(hipMemcpyAsync(mine.data(), slab, mylen * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        FDN_HIP(hipStreamSynchronize(h->stream));
+        if (copy_host(h, mine.data(), slab, mylen * sizeof(float), false)) return -1;
         if (comm->allgather_host(comm->ctx, mine.data(), all.data(), m * sizeof(float))) return fail("fdn_comm.allgather_host failed");
         std::vector<float> whole(ntot);
         for (int k = 0; k < world; k++) memcpy(whole.data() + starts[k], all.data() + (size_t)k * m, (starts[k + 1] - starts[k]) * sizeof(float));
@@ -1420,6 +1528,7 @@ FDN_API int fdn_destroy(fdn_handle h)
         FDN_DEVICE_WIDE;
         free_all(h);
         if (h->pinned) (void)hipHostFree(h->pinned);
+        if (h->bounce) (void)hipHostFree(h->bounce);
         resolve_stamps(h);
         for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
         for (hipStream_t s : h->aux_stream) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
@@ -1529,18 +1638,16 @@ FDN_API int fdn_free(fdn_handle h, void* dptr)
 FDN_API int fdn_memcpy_h2d(fdn_handle h, void* dst, const void* src, size_t bytes)
 {
     FDN_ENTER(h);
+    if (!dst || !src) return bytes ? fail("NULL pointer") : 0;
     ScopedTimer t(h, FDN_TIMER_TRANSFER);
-    FDN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
-    FDN_HIP(hipStreamSynchronize(h->stream));
-    return 0;
+    return copy_host(h, dst, src, bytes, true);
 }
 FDN_API int fdn_memcpy_d2h(fdn_handle h, void* dst, const void* src, size_t bytes)
 {
     FDN_ENTER(h);
+    if (!dst || !src) return bytes ? fail("NULL pointer") : 0;
     ScopedTimer t(h, FDN_TIMER_TRANSFER);
-    FDN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
-    FDN_HIP(hipStreamSynchronize(h->stream));
-    return 0;
+    return copy_host(h, dst, src, bytes, false);
 }
 // strided host <-> device copies (a slab of a host volume that is not contiguous: volume[:, y0:y1, :] or volume[:, :, x0:x1])
 FDN_API int fdn_memcpy2d_h2d(fdn_handle h, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t height)
@@ -1549,9 +1656,7 @@ FDN_API int fdn_memcpy2d_h2d(fdn_handle h, void* dst, size_t dpitch, const void*
     if (!dst || !src) return fail("NULL pointer");
     if (!width_bytes || !height) return 0;
     ScopedTimer t(h, FDN_TIMER_TRANSFER);
-    FDN_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, hipMemcpyHostToDevice, h->stream));
-    FDN_HIP(hipStreamSynchronize(h->stream));
-    return 0;
+    return copy_host_2d(h, dst, dpitch, const_cast<void*>(src), spitch, width_bytes, height, true);
 }
 FDN_API int fdn_memcpy2d_d2h(fdn_handle h, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t height)
 {
@@ -1559,9 +1664,7 @@ FDN_API int fdn_memcpy2d_d2h(fdn_handle h, void* dst, size_t dpitch, const void*
     if (!dst || !src) return fail("NULL pointer");
     if (!width_bytes || !height) return 0;
     ScopedTimer t(h, FDN_TIMER_TRANSFER);
-    FDN_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, hipMemcpyDeviceToHost, h->stream));
-    FDN_HIP(hipStreamSynchronize(h->stream));
-    return 0;
+    return copy_host_2d(h, const_cast<void*>(src), spitch, dst, dpitch, width_bytes, height, false);
 }
 // page-lock / release a caller's host buffer so that copies from and to it run as DMA at PCIe speed
 FDN_API int fdn_host_register(fdn_handle h, void* ptr, size_t bytes)
@@ -1890,9 +1993,8 @@ static int host_roundtrip(fdn_ctx* h, const float* in, float* out, size_t count,
     *d_in = (float*)h->vol_b.p;
     *d_out = *d_in + count;
     ScopedTimer t(h, FDN_TIMER_TRANSFER);
-    FDN_HIP(hipMemcpyAsync(*d_in, in, count * sizeof(float), hipMemcpyHostToDevice, h->stream));
     (void)out;
-    return 0;
+    return copy_host(h, *d_in, in, count * sizeof(float), true);
 }
 
 FDN_API int fdn_filter_axis(fdn_handle h, const float* in, float* out, int Z, int Y, int X, int axis,
@@ -1907,23 +2009,8 @@ FDN_API int fdn_filter_axis(fdn_handle h, const float* in, float* out, int Z, in
     if (host_roundtrip(h, in, out, count, &d_in, &d_out)) return -1;
     if (filter_axis_dev(h, d_in, d_out, Z, Y, X, axis, kernel, K, pad_value, p)) return -1;
     ScopedTimer t(h, FDN_TIMER_TRANSFER);
-    FDN_HIP(hipMemcpyAsync(out, d_out, count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    FDN_HIP(hipStreamSynchronize(h->stream));
-    return 0;
+    return copy_host(h, out, d_out, count * sizeof(float), false);
 }
-
-// Page-lock the caller's buffer for the duration of a call so that the copy is one DMA at PCIe speed instead of
-// the runtime's staged pageable copy; when the registration is refused (already registered, locked-memory limit)
-// the pageable path still works.
-struct ScopedHostRegister {
-    void* p = nullptr;
-    ScopedHostRegister(const void* ptr, size_t bytes)
-    {
-        if (bytes >= ((size_t)8 << 20) && hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) p = const_cast<void*>(ptr);
-        else (void)hipGetLastError();
-    }
-    ~ScopedHostRegister() { if (p) (void)hipHostUnregister(p); }
-};
 
 FDN_API int fdn_filter_3d(fdn_handle h, const float* in, float* out, int Z, int Y, int X,
                           const double* const kernels[3], const int K[3], float pad_value, const fdn_sweep_params* p)
@@ -1934,10 +2021,9 @@ FDN_API int fdn_filter_3d(fdn_handle h, const float* in, float* out, int Z, int 
     const size_t bytes = (size_t)Z * Y * X * sizeof(float);
     // device copies of the volume live in the handle and are reused by the next call
     if (ensure(h, h->vol_in, bytes) || ensure(h, h->vol_out, bytes)) return -1;
-    ScopedHostRegister rin(in, bytes), rout(out, bytes);
-    {
+    {   // (copy_host: page-locked for the call when the volume is 8 MB or more -- one DMA at PCIe speed --, bounced otherwise)
         ScopedTimer t(h, FDN_TIMER_TRANSFER);
-        FDN_HIP(hipMemcpyAsync(h->vol_in.p, in, bytes, hipMemcpyHostToDevice, h->stream));
+        if (copy_host(h, h->vol_in.p, in, bytes, true)) return -1;
     }
     if (filter_3d_dev(h, (const float*)h->vol_in.p, (float*)h->vol_out.p, Z, Y, X, kernels, K, pad_value, p)) {
         (void)hipStreamSynchronize(h->stream);
@@ -1945,9 +2031,8 @@ FDN_API int fdn_filter_3d(fdn_handle h, const float* in, float* out, int Z, int 
     }
     {
         ScopedTimer t(h, FDN_TIMER_TRANSFER);
-        FDN_HIP(hipMemcpyAsync(out, h->vol_out.p, bytes, hipMemcpyDeviceToHost, h->stream));
+        if (copy_host(h, out, h->vol_out.p, bytes, false)) return -1;
     }
-    FDN_HIP(hipStreamSynchronize(h->stream));
     // the two whole-volume device copies of a host-pointer call go back when they are large (2 x the volume on top of
     // the pass's own buffers would otherwise stay with a process-wide handle: other handles, torch, ranks sharing the
     // GPU need that memory); small volumes keep them, so that repeated calls do not allocate
@@ -1964,8 +2049,7 @@ FDN_API int fdn_sum_dev(fdn_handle h, const float* d_in, size_t count, double* s
     int nb = launch_sum_partials(d_in, count, (double*)h->partials.p, MAXB, h->stream);
     FDN_HIP(hipGetLastError());
     std::vector<double> host(nb);
-    FDN_HIP(hipMemcpyAsync(host.data(), h->partials.p, nb * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    FDN_HIP(hipStreamSynchronize(h->stream));
+    if (copy_host(h, host.data(), h->partials.p, nb * sizeof(double), false)) return -1;
     double s = 0;
     for (int i = 0; i < nb; i++) s += host[i];
     *sum_out = s;
@@ -2005,8 +2089,7 @@ FDN_API int fdn_stats_dev(fdn_handle h, const float* d_in, size_t count, double*
     for (int pass = 0; pass < 2; pass++) {          // pass 0: min, max, sum; pass 1: squared deviations from the mean
         const int nb = launch_stats_partials(d_in, count, mean, (double*)h->partials.p, MAXB, h->stream);
         FDN_HIP(hipGetLastError());
-        FDN_HIP(hipMemcpyAsync(host.data(), h->partials.p, (size_t)nb * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        FDN_HIP(hipStreamSynchronize(h->stream));
+        if (copy_host(h, host.data(), h->partials.p, (size_t)nb * 4 * sizeof(double), false)) return -1;
         mn = host[0]; mx = host[1]; sum = 0; sq = 0;
         for (int i = 0; i < nb; i++) {
             const double a = host[4 * i], c = host[4 * i + 1];
@@ -2032,8 +2115,7 @@ FDN_API int fdn_stats_slices_dev(fdn_handle h, const float* d_in, int nslices, s
         const int n = std::min(step, nslices - s0);
         launch_stats_slices(d_in + (size_t)s0 * slice_elems, n, slice_elems, centre, (double*)h->partials.p, h->stream);
         FDN_HIP(hipGetLastError());
-        FDN_HIP(hipMemcpyAsync(host.data(), h->partials.p, (size_t)n * B * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        FDN_HIP(hipStreamSynchronize(h->stream));
+        if (copy_host(h, host.data(), h->partials.p, (size_t)n * B * 4 * sizeof(double), false)) return -1;
         for (int s = 0; s < n; s++) {
             const double* p = host.data() + (size_t)s * B * 4;
             double mn = p[0], mx = p[1], sum = 0, sq = 0;
@@ -2132,11 +2214,10 @@ FDN_API int fdn_np_chunk_sums_dev(fdn_handle h, const float* d_in, size_t count,
         if (ensure(h, h->partials, full * sizeof(float))) return -1;
         launch_np_chunk_sums(d_in, full, (float*)h->partials.p, h->stream);
         FDN_HIP(hipGetLastError());
-        FDN_HIP(hipMemcpyAsync(sums_out, h->partials.p, full * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        if (copy_host(h, sums_out, h->partials.p, full * sizeof(float), false)) return -1;
     }
     std::vector<float> tail(rest);
-    if (rest) FDN_HIP(hipMemcpyAsync(tail.data(), d_in + full * 8192, rest * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    FDN_HIP(hipStreamSynchronize(h->stream));
+    if (rest && copy_host(h, tail.data(), d_in + full * 8192, rest * sizeof(float), false)) return -1;
     if (rest) sums_out[full] = np_pairwise_sum_f32(tail.data(), rest);
     return 0;
 }

@@ -106,6 +106,7 @@ struct fdn_transport {
     bool have_order = false;                   // ncclGroupEnd (the stream itself is the caller's and may be gone by the next gather)
     bool failed = false;                       // the communicator was aborted (a failed init, fdn_transport_abort): destroy waits for nothing
     char* stage = nullptr;                     // device staging of the host all-gather
+    char* hstage = nullptr;                    // ... and its page-locked host side (the caller's buffers are never handed to the copy engines)
     size_t stage_cap = 0;
     int count = 0;                             // ranks the communicator itself reports (ncclCommCount; SHM: ranks met at the first barrier)
     std::string device_id;                     // PCI bus id of this rank's device ("host": no device)
@@ -115,6 +116,7 @@ struct fdn_transport {
     Mapping out;                               // my outbox (read-write)
     std::vector<Mapping> in;                   // peers' outboxes (read-only)
     uint32_t my_gen = 0;
+    void* bounce = nullptr;                    // page-locked bounce buffer (hipHostMalloc) between the device and the mappings
 };
 
 namespace {
@@ -279,17 +281,20 @@ int rccl_allgather_host(fdn_transport* t, const void* send, void* recv, size_t b
     const size_t slot = (bytes + 255) & ~(size_t)255;           // `all` starts on a 256-byte boundary whatever `bytes` is
     const size_t need = slot + bytes * (size_t)t->world;
     if (t->stage_cap < need) {
-        if (t->stage) { T_HIP(hipStreamSynchronize(t->side)); T_HIP(hipFree(t->stage)); t->stage = nullptr; t->stage_cap = 0; }
+        if (t->stage) { T_HIP(hipStreamSynchronize(t->side)); T_HIP(hipFree(t->stage)); T_HIP(hipHostFree(t->hstage)); t->stage = t->hstage = nullptr; t->stage_cap = 0; }
         T_HIP(hipMalloc((void**)&t->stage, need));
+        T_HIP(hipHostMalloc((void**)&t->hstage, need, hipHostMallocDefault));
         t->stage_cap = need;
     }
     char* mine = t->stage;
     char* all = t->stage + slot;
     if (t->have_order) T_HIP(hipStreamWaitEvent(t->side, t->order, 0));
-    T_HIP(hipMemcpyAsync(mine, send, bytes, hipMemcpyHostToDevice, t->side));
+    memcpy(t->hstage, send, bytes);
+    T_HIP(hipMemcpyAsync(mine, t->hstage, bytes, hipMemcpyHostToDevice, t->side));
     T_NCCL(ncclAllGather(mine, all, bytes, ncclInt8, t->nccl, t->side));
-    T_HIP(hipMemcpyAsync(recv, all, bytes * (size_t)t->world, hipMemcpyDeviceToHost, t->side));
+    T_HIP(hipMemcpyAsync(t->hstage + slot, all, bytes * (size_t)t->world, hipMemcpyDeviceToHost, t->side));
     T_HIP(hipStreamSynchronize(t->side));
+    memcpy(recv, t->hstage + slot, bytes * (size_t)t->world);
     return 0;
 }
 
@@ -341,6 +346,27 @@ int shm_map(Mapping& m, const std::string& path, size_t len, bool writable)
 
 std::string out_path(const fdn_transport* t, int r) { return t->dir + "/out." + std::to_string(r); }
 
+// Device <-> a shared-memory mapping, through a page-locked bounce buffer of the transport's own.  The mappings are pageable
+// memory that is unmapped and mapped again as the outboxes grow: handed to hipMemcpy directly, pieces above about 1 MB would
+// be page-locked by the runtime on the fly, and such a registration outlives the mapping it was made for (the GPU memory
+// fault of round 6, flowdenoising_amd/csrc/fdn_api.hip: copy_host).
+constexpr size_t kBounceBytes = (size_t)4 << 20;
+int shm_copy(fdn_transport* t, void* dst, const void* src, size_t bytes, bool to_device)
+{
+    if (!t->bounce) T_HIP(hipHostMalloc(&t->bounce, kBounceBytes, hipHostMallocDefault));
+    for (size_t off = 0; off < bytes; off += kBounceBytes) {
+        const size_t n = std::min(kBounceBytes, bytes - off);
+        if (to_device) {
+            memcpy(t->bounce, (const char*)src + off, n);
+            T_HIP(hipMemcpy((char*)dst + off, t->bounce, n, hipMemcpyHostToDevice));
+        } else {
+            T_HIP(hipMemcpy(t->bounce, (const char*)src + off, n, hipMemcpyDeviceToHost));
+            memcpy((char*)dst + off, t->bounce, n);
+        }
+    }
+    return 0;
+}
+
 int shm_init(fdn_transport* t, const char* rendezvous)
 {
     if (!rendezvous || !*rendezvous) return fail("FDN_TRANSPORT_SHM needs a rendezvous directory");
@@ -384,7 +410,7 @@ int shm_publish(fdn_transport* t, int n, const void* const* src, const size_t* b
     for (int j = 0; j < t->world; j++) cur[j] = hd.off[j];
     for (int i = 0; i < n; i++) {
         if (!bytes[i]) continue;
-        if (device_src && t->device >= 0) T_HIP(hipMemcpy(t->out.p + cur[peer[i]], src[i], bytes[i], hipMemcpyDeviceToHost));
+        if (device_src && t->device >= 0) { if (shm_copy(t, t->out.p + cur[peer[i]], src[i], bytes[i], false)) return -1; }
         else memcpy(t->out.p + cur[peer[i]], src[i], bytes[i]);
         cur[peer[i]] += bytes[i];
     }
@@ -415,7 +441,7 @@ int shm_exchange(fdn_transport* t, int n, const fdn_msg* msgs, hipStream_t st)
         if (taken[p] + msgs[i].bytes > hd.bytes[t->rank])
             return fail("shm transport: rank %d expects %zu more bytes from rank %d than it sent (%zu)", t->rank, msgs[i].bytes, p, (size_t)hd.bytes[t->rank]);
         if (p != t->rank && shm_map(m, out_path(t, p), hd.off[t->rank] + hd.bytes[t->rank], false)) return -1;
-        if (t->device >= 0) T_HIP(hipMemcpy(msgs[i].d_buf, m.p + hd.off[t->rank] + taken[p], msgs[i].bytes, hipMemcpyHostToDevice));
+        if (t->device >= 0) { if (shm_copy(t, msgs[i].d_buf, m.p + hd.off[t->rank] + taken[p], msgs[i].bytes, true)) return -1; }
         else memcpy(msgs[i].d_buf, m.p + hd.off[t->rank] + taken[p], msgs[i].bytes);
         taken[p] += msgs[i].bytes;
     }
@@ -502,6 +528,7 @@ FDN_API int fdn_transport_destroy(fdn_transport_t t)
         if (t->side) { (void)hipStreamSynchronize(t->side); }
         if (t->nccl) (void)ncclCommDestroy(t->nccl);
         if (t->stage) (void)hipFree(t->stage);
+        if (t->hstage) (void)hipHostFree(t->hstage);
         if (t->order) (void)hipEventDestroy(t->order);
         if (t->side) (void)hipStreamDestroy(t->side);
     }
@@ -509,6 +536,7 @@ FDN_API int fdn_transport_destroy(fdn_transport_t t)
     //  never answered; waiting for it, freeing device memory (hipFree waits for the device) or ncclCommDestroy could hang.
     //  The stream, the event and the 512-byte staging block are left to the process's end, which is where such a rank is headed.)
     if (t->kind == FDN_TRANSPORT_SHM) {
+        if (t->bounce) { (void)hipSetDevice(t->device); (void)hipHostFree(t->bounce); }
         t->out.close_();
         for (auto& m : t->in) m.close_();
         if (t->ctl) munmap(t->ctl, 4096);
