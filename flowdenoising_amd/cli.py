@@ -72,6 +72,14 @@ def build_parser():
     p.add_argument("--strict_order", action="store_true",
                    help="Run OpenCV's serial horizontal running sum in the box filter instead of the direct window sum "
                         "(the one f64 summation order in which the fast kernels differ from OpenCV, ~1e-16; about 20x slower)")
+    # the two things a particular cv2 build may do differently from the modelled one: switches, so that matching a
+    # given opencv-python is an option and not a new kernel
+    p.add_argument("--opencv_fma", type=int, choices=(0, 1, 2), default=0,
+                   help="How the pyramid's blur and resize multiply-adds round (levels > 0 only): 0 two roundings (OpenCV's scalar code), "
+                        "1 fused, 2 fused on the vector body of a row (see --opencv_fma_lanes) and not on its tail")
+    p.add_argument("--opencv_fma_lanes", type=int, default=8, help="SIMD lanes of --opencv_fma 2 (8: AVX2, 4: SSE / NEON, 16: AVX-512)")
+    p.add_argument("--remap_model", type=int, choices=(0, 1), default=0,
+                   help="cv2.remap on float maps: 0 the classic 1/32-pixel coordinate table, 1 unquantised float32 bilinear")
     p.add_argument("--device", type=int, default=0, help="GPU index")
     p.add_argument("--gpus", type=int, default=1, help="Shard the volume over this many GPUs of the node")
     return p
@@ -250,6 +258,11 @@ def main(argv=None):
 
     if args.strict_order:
         os.environ["FDN_STRICT_ORDER"] = "1"   # read by libflowdn.so on its first sweep
+    if args.opencv_fma:
+        os.environ["FDN_OPENCV_FMA"] = str(args.opencv_fma)             # read by every handle at fdn_create (the ranks of --gpus N inherit them)
+        os.environ["FDN_OPENCV_FMA_LANES"] = str(args.opencv_fma_lanes)
+    if args.remap_model:
+        os.environ["FDN_REMAP_MODEL"] = str(args.remap_model)
 
     if args.show_fingerprint:  # par:425-431 hashes the script; here: the library that does the work
         from . import _lib

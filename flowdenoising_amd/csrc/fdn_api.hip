@@ -13,6 +13,7 @@
 #include <string.h>
 #include <algorithm>
 #include <array>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -298,15 +299,20 @@ static int ensure_pinned(fdn_ctx* h, size_t bytes)
 // All of them are complete when the function returns (the callers of these entry points wait anyway).
 static constexpr size_t BOUNCE_BYTES = (size_t)4 << 20;
 
+// What has been page-locked THROUGH the library (fdn_host_register): start -> bytes.  (Asking the runtime instead --
+// hipPointerGetAttributes -- works too, but it logs an error for every pageable pointer it is asked about.)  Memory a caller
+// has page-locked by other means is simply treated as pageable: bounced, which is always safe.
+static std::mutex g_locked_mu;
+static std::map<uintptr_t, size_t> g_locked;
+
 static bool host_is_locked(const void* p, size_t bytes)
 {
     if (!bytes) return true;
-    hipPointerAttribute_t a;
-    for (const char* q : {(const char*)p, (const char*)p + bytes - 1}) {
-        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
-        if (a.type != hipMemoryTypeHost) return false;
-    }
-    return true;
+    std::lock_guard<std::mutex> g(g_locked_mu);
+    auto it = g_locked.upper_bound((uintptr_t)p);
+    if (it == g_locked.begin()) return false;
+    --it;
+    return (uintptr_t)p + bytes <= it->first + it->second;
 }
 
 static int ensure_bounce(fdn_ctx* h)
@@ -480,9 +486,10 @@ static int check_params(const fdn_sweep_params* p, int K)
 }
 
 // fdn_sweep_params -> what the folding kernels need; pad slices in the coordinates of a stack of S + 2r slices
-static WarpMode warp_mode_of(const fdn_sweep_params* p, int S, int r)
+static WarpMode warp_mode_of(const fdn_ctx* h, const fdn_sweep_params* p, int S, int r)
 {
     WarpMode wm;
+    wm.model = h->tn.remap_model;
     wm.kind = p->warp_mode;
     if (wm.kind == FDN_WARP_FIXED_U8) { wm.kind = FDN_WARP_ROUND_INT; wm.fixed8 = 1; wm.lo = 0.f; wm.hi = 255.f; return wm; }   // the ROUND_INT kernels, their remap in 8-bit fixed point
     if (wm.kind == FDN_WARP_F64_PADDED) { wm.pad_lo = p->pad_lo; wm.pad_hi = S + 2 * r - p->pad_hi; wm.pad64 = p->pad64; }
@@ -573,7 +580,7 @@ static int resize_dev(fdn_ctx* h, const float* in, int sh, int sw, float* out, i
         resize_area_tab(in, sh, sw, out, dh, dw, cn, nimg, h->area.x_si, h->area.x_alpha, h->area.x_start,
                         h->area.y_si, h->area.y_alpha, h->area.y_start, apply_ps, ps, h->stream);
     } else {
-        resize_images(in, sh, sw, out, dh, dw, cn, nimg, interp, apply_ps, ps, h->stream);
+        resize_images(in, sh, sw, out, dh, dw, cn, nimg, interp, apply_ps, ps, h->stream, h->tn.fma);
     }
     return 0;
 }
@@ -602,9 +609,9 @@ static int build_R_pyramid(fdn_ctx* h, const float* imgs, int nimg, int H, int W
         for (int s0 = 0; s0 < nimg; s0 += chunk) {
             int n = std::min(chunk, nimg - s0);
             if (lv[k].h < H && lv[k].w < W) {     // always, for a pyramid level: blur only where the resize reads
-                launch_blur_resize(imgs + (size_t)s0 * HW, tmp, small, n, H, W, lv[k].h, lv[k].w, bt, h->stream);
+                launch_blur_resize(imgs + (size_t)s0 * HW, tmp, small, n, H, W, lv[k].h, lv[k].w, bt, h->stream, h->tn.fma);
             } else {
-                launch_gaussian_blur(imgs + (size_t)s0 * HW, tmp, blurred, n, H, W, bt, h->stream);
+                launch_gaussian_blur(imgs + (size_t)s0 * HW, tmp, blurred, n, H, W, bt, h->stream, h->tn.fma);
                 if (resize_dev(h, blurred, H, W, small, lv[k].h, lv[k].w, 1, n, 1, false, 1.0)) return -1;
             }
             launch_polyexp(small, (float*)h->Rpyr.p + lv[k].r_off + (size_t)s0 * 5 * lv[k].h * lv[k].w, n, lv[k].h, lv[k].w, pc, h->stream);
@@ -767,7 +774,7 @@ static int chain_step_iter(fdn_ctx* h, const std::vector<PyrLevel>& lv, const fl
             float* fout = fin == A ? B : A;
             ScopedTimer t(h, FDN_TIMER_ITER);
             if (launch_farneback_iter(Rk, stack, fin, last && !keep ? nullptr : fout, last ? acc : nullptr, pb, lv[k].h, lv[k].w,
-                                      winsize, weight, h->stream, ch, cw, wm))
+                                      winsize, weight, h->stream, ch, cw, wm, h->tn.fma))
                 return fail("k_farneback_iter could not be launched (winsize %d needs %zu bytes of LDS)", winsize, iter_lds_bytes(winsize / 2, true));
             fin = fout; ch = cw = 0;
         }
@@ -849,7 +856,7 @@ static int sweep_stack(fdn_ctx* h, const float* stack, float* out, int S, int H,
     hipStream_t st = h->stream;
     if (p->warp_mode == FDN_WARP_F64_PADDED && (long)p->pad_lo + p->pad_hi > (long)S + 2 * r)
         return fail("pad_lo + pad_hi = %d + %d exceeds the stack's %d slices", p->pad_lo, p->pad_hi, S + 2 * r);
-    const WarpMode wm_all = warp_mode_of(p, S, r);   // pad slices in the coordinates of the whole stack
+    const WarpMode wm_all = warp_mode_of(h, p, S, r);   // pad slices in the coordinates of the whole stack
     // (an integer volume's accumulate -- float64 padded volume / integer images -- is part of the Farneback kernels' final
     //  stage too: fold_warped<WM>; only the per-stage path folds with k_sweep_side)
 
@@ -1513,6 +1520,9 @@ FDN_API int fdn_create(int device, fdn_handle* out)
     h->tn.fused_occ = env_int("FDN_FUSED_OCC");
     h->tn.lds_pad = (unsigned)env_int("FDN_LDS_PAD");
     h->tn.sub_batches = std::min((int)fdn_ctx::MAX_SUB, std::max(0, env_int("FDN_SUB_BATCHES")));
+    h->tn.fma.mode = std::min(2, std::max(0, env_int("FDN_OPENCV_FMA")));
+    if (getenv("FDN_OPENCV_FMA_LANES")) h->tn.fma.lanes = std::min(64, std::max(1, env_int("FDN_OPENCV_FMA_LANES")));
+    h->tn.remap_model = env_int("FDN_REMAP_MODEL") == 1 ? 1 : 0;
     if (const char* tp = getenv("FDN_LAUNCH_TRACE")) h->trace_fd = open(tp, O_CREAT | O_WRONLY | O_APPEND, 0644);
     *out = h;
     return 0;
@@ -1600,8 +1610,11 @@ FDN_API int fdn_set_option(fdn_handle h, const char* name, long value)
     else if (!strcmp(name, "fused_occ")) { if (value && (value < 3 || value > 5) && value != 8) return fail("fused_occ must be 0, 3, 4, 5 or 8"); h->tn.fused_occ = (int)value; }
     else if (!strcmp(name, "lds_pad")) { if (value < 0 || value > 160 * 1024) return fail("lds_pad out of range"); h->tn.lds_pad = (unsigned)value; }
     else if (!strcmp(name, "shard_loopback")) h->tn.shard_loopback = value != 0;
+    else if (!strcmp(name, "opencv_fma")) { if (value < 0 || value > 2) return fail("opencv_fma must be 0 (two roundings), 1 (fused) or 2 (fused on the vector body of a row)"); h->tn.fma.mode = (int)value; }
+    else if (!strcmp(name, "opencv_fma_lanes")) { if (value < 1 || value > 64) return fail("opencv_fma_lanes must be 1 .. 64"); h->tn.fma.lanes = (int)value; }
+    else if (!strcmp(name, "remap_model")) { if (value < 0 || value > 1) return fail("remap_model must be 0 (1/32-pixel table) or 1 (unquantised float32 bilinear)"); h->tn.remap_model = (int)value; }
     else if (!strcmp(name, "sub_batches")) { if (value < 0 || value > fdn_ctx::MAX_SUB) return fail("sub_batches must be 0 (automatic) or 1 .. %d", (int)fdn_ctx::MAX_SUB); h->tn.sub_batches = (int)value; }
-    else return fail("unknown option '%s' (strict_order, path, fused_occ, lds_pad, shard_loopback, sub_batches)", name);
+    else return fail("unknown option '%s' (strict_order, path, fused_occ, lds_pad, shard_loopback, sub_batches, opencv_fma, opencv_fma_lanes, remap_model)", name);
     return 0;
 }
 FDN_API int fdn_get_option(fdn_handle h, const char* name, long* value_out)
@@ -1614,6 +1627,9 @@ FDN_API int fdn_get_option(fdn_handle h, const char* name, long* value_out)
     else if (!strcmp(name, "lds_pad")) *value_out = (long)h->tn.lds_pad;
     else if (!strcmp(name, "shard_loopback")) *value_out = h->tn.shard_loopback;
     else if (!strcmp(name, "sub_batches")) *value_out = h->tn.sub_batches;
+    else if (!strcmp(name, "opencv_fma")) *value_out = h->tn.fma.mode;
+    else if (!strcmp(name, "opencv_fma_lanes")) *value_out = h->tn.fma.lanes;
+    else if (!strcmp(name, "remap_model")) *value_out = h->tn.remap_model;
     else if (!strcmp(name, "last_sub_batches")) *value_out = h->last_sub_batches;     // read-only: what the last sweep ran with
     else if (!strcmp(name, "compute_units")) *value_out = h->tn.cus;                   // read-only
     else return fail("unknown option '%s'", name);
@@ -1676,12 +1692,24 @@ FDN_API int fdn_host_register(fdn_handle h, void* ptr, size_t bytes)
         (void)hipGetLastError();   // so the runtime's sticky last-error must not surface in their next launch check
         return fail("hipHostRegister(%zu bytes): %s", bytes, hipGetErrorString(e));
     }
+    std::lock_guard<std::mutex> g(g_locked_mu);
+    g_locked[(uintptr_t)ptr] = bytes;
     return 0;
 }
 FDN_API int fdn_host_unregister(fdn_handle h, void* ptr)
 {
-    FDN_ENTER(h);
+    // A registration belongs to the process, not to the handle that made it: it can be released through any handle, and
+    // through none (h == NULL) -- a buffer must never stay registered because the handle it was registered through is gone.
+    std::unique_lock<std::recursive_mutex> enter_guard_;
+    if (h) {
+        enter_guard_ = std::unique_lock<std::recursive_mutex>(h->mu);
+        FDN_HIP(hipSetDevice(h->device));
+    }
     if (!ptr) return fail("NULL pointer");
+    {
+        std::lock_guard<std::mutex> g(g_locked_mu);
+        g_locked.erase((uintptr_t)ptr);
+    }
     const hipError_t e = hipHostUnregister(ptr);
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -1842,7 +1870,7 @@ FDN_API int fdn_warp_strided(fdn_handle h, const float* reference, ptrdiff_t rs,
         memcpy(stage + HW, flow, HW * 8);
         FDN_HIP(hipMemcpyAsync(d_src, stage, HW * 12, hipMemcpyHostToDevice, st));
     }
-    launch_warp(d_src, d_flow, d_dst, H, W, st);
+    launch_warp(d_src, d_flow, d_dst, H, W, st, h->tn.remap_model);
     FDN_HIP(hipGetLastError());
     ScopedTimer t(h, FDN_TIMER_TRANSFER);
     FDN_HIP(hipMemcpyAsync(stage + 3 * HW, d_dst, HW * 4, hipMemcpyDeviceToHost, st));
@@ -1913,7 +1941,7 @@ FDN_API int fdn_warp_typed(fdn_handle h, const void* reference, int depth, ptrdi
             FDN_HIP(hipMemcpyAsync(d_src, stage, HW * 8, hipMemcpyHostToDevice, st));
             FDN_HIP(hipMemcpyAsync(d_flow, stage + 2 * HW, HW * 8, hipMemcpyHostToDevice, st));
         }
-        launch_warp_f64(d_src, d_flow, d_dst, H, W, st);
+        launch_warp_f64(d_src, d_flow, d_dst, H, W, st, h->tn.remap_model);
         FDN_HIP(hipGetLastError());
         ScopedTimer t(h, FDN_TIMER_TRANSFER);
         FDN_HIP(hipMemcpyAsync(stage + HW, d_dst, HW * 8, hipMemcpyDeviceToHost, st));
@@ -1936,7 +1964,7 @@ FDN_API int fdn_warp_typed(fdn_handle h, const void* reference, int depth, ptrdi
         FDN_HIP(hipMemcpyAsync(d_src, stage, HW * 12, hipMemcpyHostToDevice, st));
     }
     if (depth == FDN_DEPTH_U8) launch_warp_u8(d_src, d_flow, d_dst, H, W, st);     // 8-bit fixed-point interpolation: integers already
-    else launch_warp(d_src, d_flow, d_dst, H, W, st);
+    else launch_warp(d_src, d_flow, d_dst, H, W, st, h->tn.remap_model);
     FDN_HIP(hipGetLastError());
     ScopedTimer t(h, FDN_TIMER_TRANSFER);
     FDN_HIP(hipMemcpyAsync(stage + 3 * HW, d_dst, HW * 4, hipMemcpyDeviceToHost, st));
@@ -1966,7 +1994,7 @@ FDN_API int fdn_warp_dev(fdn_handle h, const float* d_reference, ptrdiff_t rs, p
         src = (const float*)h->pair.p;
     }
     if (src == d_dst) return fail("reference and dst must not alias");
-    launch_warp(src, d_flow, d_dst, H, W, h->stream);
+    launch_warp(src, d_flow, d_dst, H, W, h->stream, h->tn.remap_model);
     FDN_HIP(hipGetLastError());
     return 0;
 }

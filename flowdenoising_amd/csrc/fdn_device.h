@@ -272,6 +272,20 @@ static __device__ __forceinline__ float2 solve_flow(const double a[5], double sc
 // cv::resize INTER_LINEAR of a 2-channel f32 image (HResizeLinear then VResizeLinear, f32
 // coefficients) sampled at one destination pixel, times `ps` in f64: calc()'s upsampling of the flow
 // between pyramid levels.  scale_x = sw / dw, scale_y = sh / dh.
+// a * b + c with one rounding (fused) or two: the "opencv_fma" option (FmaMode, fdn_internal.h).  OpenCV's SIMD filter and
+// resize loops use v_muladd, which is a fused multiply-add on AVX2 / FMA3 builds and two operations in their scalar row
+// tails; which of the two a given cv2 wheel runs at a given pixel is one of the unknowns of an unpinned cv2.
+// i: the element's index in its row of `width` elements (channels interleaved): mode 1 fuses everywhere, mode 2 on the
+// vector body -- the first (width / lanes) * lanes elements -- and not on the tail.
+static __device__ __forceinline__ bool fma_at(const FmaMode& fm, int i, int width)
+{
+    return fm.mode == 1 || (fm.mode == 2 && i < width / fm.lanes * fm.lanes);
+}
+static __device__ __forceinline__ float madf(bool fused, float a, float b, float c)
+{
+    return fused ? __builtin_fmaf(a, b, c) : a * b + c;
+}
+
 struct LinearTap { int s0, s1; float a0, a1; };
 static __device__ __forceinline__ LinearTap linear_tap(int d, double scale, int n)
 {
@@ -285,14 +299,16 @@ static __device__ __forceinline__ LinearTap linear_tap(int d, double scale, int 
     t.s0 = s; t.s1 = s + 1 < n ? s + 1 : n - 1; t.a1 = f; t.a0 = 1.f - f;
     return t;
 }
-static __device__ __forceinline__ float2 resize_linear_flow(const float* __restrict__ src, int sw, const LinearTap& tx, const LinearTap& ty, double ps)
+// dx, dw: the destination column and row length (the "opencv_fma" option goes by the element's place in its row: VResizeLinear)
+static __device__ __forceinline__ float2 resize_linear_flow(const float* __restrict__ src, int sw, const LinearTap& tx, const LinearTap& ty, double ps,
+                                                            const FmaMode& fm = FmaMode(), int dx = 0, int dw = 0)
 {
     const unsigned r0 = (unsigned)ty.s0 * (unsigned)sw, r1 = (unsigned)ty.s1 * (unsigned)sw;
     const float2 p00 = ld_off<float2>(src, (r0 + tx.s0) * 8u), p01 = ld_off<float2>(src, (r0 + tx.s1) * 8u);
     const float2 p10 = ld_off<float2>(src, (r1 + tx.s0) * 8u), p11 = ld_off<float2>(src, (r1 + tx.s1) * 8u);
     float2 v;
-    v.x = (p00.x * tx.a0 + p01.x * tx.a1) * ty.a0 + (p10.x * tx.a0 + p11.x * tx.a1) * ty.a1;
-    v.y = (p00.y * tx.a0 + p01.y * tx.a1) * ty.a0 + (p10.y * tx.a0 + p11.y * tx.a1) * ty.a1;
+    v.x = madf(fma_at(fm, 2 * dx, 2 * dw), p00.x * tx.a0 + p01.x * tx.a1, ty.a0, (p10.x * tx.a0 + p11.x * tx.a1) * ty.a1);
+    v.y = madf(fma_at(fm, 2 * dx + 1, 2 * dw), p00.y * tx.a0 + p01.y * tx.a1, ty.a0, (p10.y * tx.a0 + p11.y * tx.a1) * ty.a1);
     v.x = (float)((double)v.x * ps);
     v.y = (float)((double)v.y * ps);
     return v;
@@ -300,22 +316,34 @@ static __device__ __forceinline__ float2 resize_linear_flow(const float* __restr
 
 // remap in two halves so that a kernel can issue the four tap loads one pipeline step before it
 // combines them: remap_issue computes the quantised position and loads, remap_finish weights.
+// (ax, ay): the 5-bit table indices of the classic path; with the unquantised model (WarpMode::model = 1) the BITS of the two
+// float32 fractions instead -- the same registers, so that the Farneback kernels' final stage does not grow)
 struct RemapTaps { float v0, v1, v2, v3; int ax, ay; };
 
 // PAIRS: fetch the two taps of a row with one 8-byte load.  Half the gather instructions -- what a memory-bound kernel
 // needs (k_sweep_side: 8.6 -> 6.1 ms) -- for four selects more, which the VALU-bound Farneback kernels cannot afford
 // (k_farneback_fused: 17.0 -> 17.9 ms): those keep the four dword loads.  Same values either way.
+// unq (wave-uniform; the "remap_model" option): the float-map remap that does NOT round the coordinates to 1/32 pixel --
+// plain float32 bilinear interpolation at the map position (remap_finish below) -- a model of the reworked linear remap
+// newer OpenCV releases are reported to ship; the second known unknown of an unpinned cv2.
 template <bool PAIRS = false>
-static __device__ __forceinline__ void remap_issue(const float* __restrict__ src, int H, int W, int x, int y, float2 f, RemapTaps& r)
+static __device__ __forceinline__ void remap_issue(const float* __restrict__ src, int H, int W, int x, int y, float2 f, RemapTaps& r, bool unq = false)
 {
     float mx = (float)((double)f.x + (double)x);
     float my = (float)((double)f.y + (double)y);
-    // cvRound(v * INTER_TAB_SIZE); bounded so the int conversion is defined for wild flows
-    float qx = fminf(fmaxf(rintf(mx * 32.f), -2147483520.f), 2147483520.f);
-    float qy = fminf(fmaxf(rintf(my * 32.f), -2147483520.f), 2147483520.f);
-    int sx = (int)qx, sy = (int)qy;
-    r.ax = sx & 31; r.ay = sy & 31;
-    int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);
+    int ix, iy;
+    if (unq) {
+        const float flx = floorf(mx), fly = floorf(my);
+        r.ax = __float_as_int(mx - flx); r.ay = __float_as_int(my - fly);
+        ix = (int)fminf(fmaxf(flx, -32768.f), 32767.f); iy = (int)fminf(fmaxf(fly, -32768.f), 32767.f);
+    } else {
+        // cvRound(v * INTER_TAB_SIZE); bounded so the int conversion is defined for wild flows
+        float qx = fminf(fmaxf(rintf(mx * 32.f), -2147483520.f), 2147483520.f);
+        float qy = fminf(fmaxf(rintf(my * 32.f), -2147483520.f), 2147483520.f);
+        int sx = (int)qx, sy = (int)qy;
+        r.ax = sx & 31; r.ay = sy & 31;
+        ix = clampi(sx >> 5, -32768, 32767); iy = clampi(sy >> 5, -32768, 32767);
+    }
     int xa = clamp0u(ix, W - 1), xb = clamp0u(ix + 1, W - 1);
     int ya = clamp0u(iy, H - 1), yb = clamp0u(iy + 1, H - 1);
     const unsigned oa = __umul24((unsigned)ya, (unsigned)W), ob = __umul24((unsigned)yb, (unsigned)W);   // H, W < 2^24
@@ -332,8 +360,13 @@ static __device__ __forceinline__ void remap_issue(const float* __restrict__ src
     }
 }
 
-static __device__ __forceinline__ float remap_finish(const RemapTaps& r)
+static __device__ __forceinline__ float remap_finish(const RemapTaps& r, bool unq = false)
 {
+    if (unq) {     // two float32 lerps: along x in both rows, then along y
+        const float fx = __int_as_float(r.ax), fy = __int_as_float(r.ay);
+        const float top = r.v0 * (1.f - fx) + r.v1 * fx, bot = r.v2 * (1.f - fx) + r.v3 * fx;
+        return top * (1.f - fy) + bot * fy;
+    }
     float tx1 = (float)r.ax * (1.f / 32), tx0 = 1.f - tx1;
     float ty1 = (float)r.ay * (1.f / 32), ty0 = 1.f - ty1;
     float w0 = ty0 * tx0, w1 = ty0 * tx1, w2 = ty1 * tx0, w3 = ty1 * tx1;
@@ -354,8 +387,14 @@ static __device__ __forceinline__ float remap_finish_u8(const RemapTaps& r)
 
 // cv2.remap of a CV_64F image (remapBilinear<Cast<double, double>, ., float>): the float table weights widened, the four
 // products and three sums in double, no rounding to float.  pad: the image is the constant `padv` (a mean-pad slice).
-static __device__ __forceinline__ double remap_finish_f64(const RemapTaps& r, bool pad, double padv)
+static __device__ __forceinline__ double remap_finish_f64(const RemapTaps& r, bool pad, double padv, bool unq = false)
 {
+    if (unq) {     // the same two lerps on a CV_64F image: values and sums in double, the float32 fractions widened
+        const float fx = __int_as_float(r.ax), fy = __int_as_float(r.ay);
+        const double v0 = pad ? padv : (double)r.v0, v1 = pad ? padv : (double)r.v1, v2 = pad ? padv : (double)r.v2, v3 = pad ? padv : (double)r.v3;
+        const double top = v0 * (double)(1.f - fx) + v1 * (double)fx, bot = v2 * (double)(1.f - fx) + v3 * (double)fx;
+        return top * (double)(1.f - fy) + bot * (double)fy;
+    }
     float tx1 = (float)r.ax * (1.f / 32), tx0 = 1.f - tx1;
     float ty1 = (float)r.ay * (1.f / 32), ty0 = 1.f - ty1;
     float w0 = ty0 * tx0, w1 = ty0 * tx1, w2 = ty1 * tx0, w3 = ty1 * tx1;
@@ -364,10 +403,19 @@ static __device__ __forceinline__ double remap_finish_f64(const RemapTaps& r, bo
 }
 
 // the same remap for a CV_64F image held as doubles (fdn_warp_typed): coordinates and weights as remap_issue / remap_finish_f64
-static __device__ __forceinline__ double remap_sample_f64(const double* __restrict__ src, int H, int W, int x, int y, float2 f)
+static __device__ __forceinline__ double remap_sample_f64(const double* __restrict__ src, int H, int W, int x, int y, float2 f, bool unq = false)
 {
     float mx = (float)((double)f.x + (double)x);
     float my = (float)((double)f.y + (double)y);
+    if (unq) {
+        const float flx = floorf(mx), fly = floorf(my);
+        const float fx = mx - flx, fy = my - fly;
+        const int ix = (int)fminf(fmaxf(flx, -32768.f), 32767.f), iy = (int)fminf(fmaxf(fly, -32768.f), 32767.f);
+        const int xa = clampi(ix, 0, W - 1), xb = clampi(ix + 1, 0, W - 1), ya = clampi(iy, 0, H - 1), yb = clampi(iy + 1, 0, H - 1);
+        const size_t oa = (size_t)ya * W, ob = (size_t)yb * W;
+        const double top = src[oa + xa] * (double)(1.f - fx) + src[oa + xb] * (double)fx, bot = src[ob + xa] * (double)(1.f - fx) + src[ob + xb] * (double)fx;
+        return top * (double)(1.f - fy) + bot * (double)fy;
+    }
     float qx = fminf(fmaxf(rintf(mx * 32.f), -2147483520.f), 2147483520.f);
     float qy = fminf(fmaxf(rintf(my * 32.f), -2147483520.f), 2147483520.f);
     int sx = (int)qx, sy = (int)qy;
@@ -390,21 +438,23 @@ static __device__ __forceinline__ double remap_sample_f64(const double* __restri
 //   2  par on an integer MRC: the neighbour is an integer image: remap rounds half to even and saturates (lo, hi)
 template <int WM>
 static __device__ __forceinline__ float fold_warped(const float* __restrict__ src, int H, int W, int x, int y, float2 f, float acc_old,
-                                                    double weight, bool pad, double pad64, float lo, float hi, bool fixed8 = false)
+                                                    double weight, bool pad, double pad64, float lo, float hi, bool fixed8 = false, bool unq = false)
 {
     RemapTaps r;
-    remap_issue<false>(src, H, W, x, y, f, r);
-    if (WM == 1) return (float)((double)acc_old + remap_finish_f64(r, pad, pad64) * weight);
+    // (8-bit images keep their fixed-point table in either remap model: the unquantised model is about float maps on float arithmetic)
+    const bool u = unq && !(WM == 2 && fixed8);
+    remap_issue<false>(src, H, W, x, y, f, r, u);
+    if (WM == 1) return (float)((double)acc_old + remap_finish_f64(r, pad, pad64, u) * weight);
     //   2  ... and a uint8 one (fixed8, wave-uniform): cv2.remap's 8-bit fixed point, an integer already
-    if (WM == 2) return (float)((double)acc_old + (double)(fixed8 ? remap_finish_u8(r) : fminf(fmaxf(rintf(remap_finish(r)), lo), hi)) * weight);
-    return (float)((double)acc_old + (double)remap_finish(r) * weight);
+    if (WM == 2) return (float)((double)acc_old + (double)(fixed8 ? remap_finish_u8(r) : fminf(fmaxf(rintf(remap_finish(r, u)), lo), hi)) * weight);
+    return (float)((double)acc_old + (double)remap_finish(r, u) * weight);
 }
 
-static __device__ __forceinline__ float remap_sample(const float* __restrict__ src, int H, int W, int x, int y, float2 f)
+static __device__ __forceinline__ float remap_sample(const float* __restrict__ src, int H, int W, int x, int y, float2 f, bool unq = false)
 {
     RemapTaps r;
-    remap_issue<false>(src, H, W, x, y, f, r);
-    return remap_finish(r);
+    remap_issue<false>(src, H, W, x, y, f, r, unq);
+    return remap_finish(r, unq);
 }
 
 } // namespace fdn

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
         const LinearTap ftx = FIN == 2 ? linear_tap(xc, fs.sx, fs.w) : LinearTap{};
         auto load_flow = [&](int row) __attribute__((always_inline)) -> float2 {
             if (FIN == 1) return ld_off<float2>(flow_in, ((unsigned)row * (unsigned)W + (unsigned)xc) * 8u);
-            if (FIN == 2) return resize_linear_flow(flow_in, fs.w, ftx, linear_tap(row, fs.sy, fs.h), 2.0);
+            if (FIN == 2) return resize_linear_flow(flow_in, fs.w, ftx, linear_tap(row, fs.sy, fs.h), 2.0, fs.fm, xc, W);
             return make_float2(0.f, 0.f);
         };
         const int wcol0 = clampi(xw0 + lane, 0, W - 1);        // image columns this lane loads into the window
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
                             // (WM: the dtype semantics of an integer volume, fold_warped in fdn_device.h; the neighbour's stack index decides `pad`)
                             const int q = pb.t0 + b + pd;
                             const bool pad = WM == 1 && (q < wm.pad_lo || q >= wm.pad_hi);
-                            const float acc_new = fold_warped<WM>(img1, H, W, xc, y, f, acc_old, weight, pad, wm.pad64, wm.lo, wm.hi, wm.fixed8 != 0);
+                            const float acc_new = fold_warped<WM>(img1, H, W, xc, y, f, acc_old, weight, pad, wm.pad64, wm.lo, wm.hi, wm.fixed8 != 0, wm.model == 1);
                             if (owner) {
                                 if (flow_out) st_off(flow_out, o * 8u, f);
                                 st_off(acc, o * 4u, acc_new);
@@ -554,7 +554,7 @@ void launch_farneback_fused(const float* Rstack, const float* stack, const float
 {
     if (pb.npairs <= 0) return;
     (void)iters;
-    FlowSource fs{coarse_h, coarse_w, coarse_h > 0 ? (double)coarse_w / W : 1.0, coarse_h > 0 ? (double)coarse_h / H : 1.0};
+    FlowSource fs{coarse_h, coarse_w, coarse_h > 0 ? (double)coarse_w / W : 1.0, coarse_h > 0 ? (double)coarse_h / H : 1.0, tn.fma};
     const double scale = 1. / ((double)winsize * winsize);
     const int mh = winsize / 2;
 #ifndef FDN_ONLY_MH2   // (experiment builds leave the other windows out: half the compile time)

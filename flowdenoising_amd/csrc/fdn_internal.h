@@ -7,6 +7,14 @@
 
 namespace fdn {
 
+// The "opencv_fma" option: how the multiply-adds of cv::GaussianBlur's two passes and of cv::resize's vertical pass round
+// (the pyramid of levels > 0 only; level 0's blur taps are powers of two and fusing changes nothing there):
+//   0  two roundings everywhere (the reading of OpenCV's scalar code; the default)
+//   1  fused everywhere (a build whose vector loops use FMA and cover whole rows)
+//   2  fused on the vector body of a row -- its first (width / lanes) * lanes elements --, two roundings on the tail
+//      (v_muladd in the SIMD loop, plain C after it; lanes = 8 for AVX2, 4 for SSE / NEON, 16 for AVX-512)
+struct FmaMode { int mode = 0; int lanes = 8; };
+
 // Polynomial-expansion constants (OpenCV FarnebackPrepareGaussian), passed by value.
 struct PolyConsts {
     int n;                       // half-width: taps -n..n
@@ -62,7 +70,8 @@ void launch_update_flow(const float* Rstack, const float* Min, float* Mout, floa
 // [pad_hi, ...) hold the float64 value pad64; 2 = the neighbour is an integer image (par on an integer MRC): remap's
 // result is rounded half-to-even and saturated to [lo, hi].
 // fixed8 (with kind 2): the neighbour is a uint8 image: remap in OpenCV's 8-bit fixed point instead of float + rounding.
-struct WarpMode { int kind = 0; int pad_lo = 0, pad_hi = 1 << 30; double pad64 = 0.; float lo = 0.f, hi = 0.f; int fixed8 = 0; };
+// model (the "remap_model" option): 0 = cv2.remap's classic 1/32-pixel coordinate table, 1 = unquantised float32 bilinear.
+struct WarpMode { int kind = 0; int pad_lo = 0, pad_hi = 1 << 30; double pad64 = 0.; float lo = 0.f, hi = 0.f; int fixed8 = 0; int model = 0; };
 void launch_sweep_side(const float* stack, const float* flows, float* acc, PairBatch pb, int nsteps, int first_step,
                        int H, int W, const double* weights, hipStream_t st, const WarpMode& wm = WarpMode());
 // acc[b] = f32( f64(acc[b]) + f64(stack[t0 + b + d]) * weight )   (centre tap, no-OF taps)
@@ -71,11 +80,11 @@ void launch_axpy_slices(const float* stack, float* acc, PairBatch pb, int H, int
 // v = trunc(v) clamped to [lo, hi]: a float32 result stored into an integer volume (par:131, par:287)
 void launch_trunc_clamp(float* v, size_t count, float lo, float hi, hipStream_t st);
 // dst(y,x) = remap(src, flow)  single image (fdn_warp)
-void launch_warp(const float* src, const float* flow, float* dst, int H, int W, hipStream_t st);
+void launch_warp(const float* src, const float* flow, float* dst, int H, int W, hipStream_t st, int model = 0);
 // the same for a CV_8U image (values 0..255 held as floats): cv2.remap's 8-bit fixed-point interpolation
 void launch_warp_u8(const float* src, const float* flow, float* dst, int H, int W, hipStream_t st);
 // the same for a CV_64F image: double in, double out (cv2.remap's Cast<double, double> path)
-void launch_warp_f64(const double* src, const float* flow, double* dst, int H, int W, hipStream_t st);
+void launch_warp_f64(const double* src, const float* flow, double* dst, int H, int W, hipStream_t st, int model = 0);
 
 // Per-handle switches: read from the environment once, at fdn_create, and changed with fdn_set_option
 // (tests and experiments; every path gives the same bits except strict_order).
@@ -89,6 +98,8 @@ struct Tuning {
     int shard_loopback = 0;  // fdn_filter_3d_sharded: the blocks a rank keeps also travel through the transport (send to self)
     int sub_batches = 0;     // FDN_SUB_BATCHES: 0 = automatic (two when a launch of the pass is under four rounds of workgroup slots),
                              // 1 = one stream, 2 = the target slices of a batch as two independent sub-batches on two streams
+    FmaMode fma;             // "opencv_fma" / "opencv_fma_lanes" (FDN_OPENCV_FMA, FDN_OPENCV_FMA_LANES)
+    int remap_model = 0;     // "remap_model" (FDN_REMAP_MODEL): WarpMode::model of every warp
     long occ_blocks = 0;     // set by the sweep while sub-batches run: the workgroups of BOTH sub-batches' launches, which is
                              // what the occupancy choice of the 3-iteration kernel goes by (0: the launch's own grid)
 };
@@ -110,10 +121,10 @@ bool iter_supported(int winsize, int H, int W);
 size_t iter_lds_bytes(int mh, bool acc);
 int launch_farneback_iter(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
                           PairBatch pb, int H, int W, int winsize, double weight, hipStream_t st,
-                          int coarse_h = 0, int coarse_w = 0, const WarpMode& wm = WarpMode());
+                          int coarse_h = 0, int coarse_w = 0, const WarpMode& wm = WarpMode(), const FmaMode& fm = FmaMode());
 
 // where the fused kernel's initial flow comes from when it is the next coarser pyramid level's result
-struct FlowSource { int h, w; double sx, sy; };   // h == 0: flow_in has the image's own size
+struct FlowSource { int h, w; double sx, sy; FmaMode fm; };   // h == 0: flow_in has the image's own size; fm: how the upsampling rounds
 
 void launch_fill(float* dst, float value, size_t count, hipStream_t st);
 // out[r][c] (contiguous H x W) = in[r * rs + c * cs]  (strides in elements; a slice view of a volume)
@@ -135,17 +146,17 @@ int launch_sum_partials(const float* in, size_t count, double* partials, int max
 
 // pyramid pieces (levels > 0)
 void launch_gaussian_blur(const float* in, float* tmp, float* out, int nimg, int H, int W,
-                          const BlurTaps& bt, hipStream_t st);
+                          const BlurTaps& bt, hipStream_t st, const FmaMode& fm = FmaMode());
 // small = resize(GaussianBlur(in, bt), (dw, dh), INTER_LINEAR) with the blur evaluated only where the resize reads it
 // (a strict shrink: dw < W, dh < H); tmp: nimg * H * 2 dw floats
 void launch_blur_resize(const float* in, float* tmp, float* small, int nimg, int H, int W, int dh, int dw,
-                        const BlurTaps& bt, hipStream_t st);
+                        const BlurTaps& bt, hipStream_t st, const FmaMode& fm = FmaMode());
 // cv::resize as FarnebackOpticalFlowImpl::calc uses it, nimg images of cn interleaved
 // channels: interp 1 = INTER_LINEAR (an exact 2x2 shrink is promoted to area, as cv::resize
 // does), 3 = INTER_AREA (integer ratios on this path).  If apply_ps, each result is then
 // multiplied by ps in f64 (the "flow *= scale" of calc).
 void resize_images(const float* in, int sh, int sw, float* out, int dh, int dw, int cn, int nimg,
-                   int interp, bool apply_ps, double ps, hipStream_t st);
+                   int interp, bool apply_ps, double ps, hipStream_t st, const FmaMode& fm = FmaMode());
 
 // true when resize_images can do this (interp, size pair) itself; INTER_AREA with a non-integer
 // shrink ratio needs the table form below

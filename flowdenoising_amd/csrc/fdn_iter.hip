@@ -126,7 +126,7 @@ __global__ __launch_bounds__(ACC ? 192 : 128) void k_farneback_iter(const float*
         const LinearTap ftx = FIN == 2 ? linear_tap(xc, fs.sx, fs.w) : LinearTap{};
         auto load_flow = [&](int row) __attribute__((always_inline)) -> float2 {
             if (FIN == 1) return ld_off<float2>(flow_in, ((unsigned)row * (unsigned)W + (unsigned)xc) * 8u);
-            if (FIN == 2) return resize_linear_flow(flow_in, fs.w, ftx, linear_tap(row, fs.sy, fs.h), 2.0);
+            if (FIN == 2) return resize_linear_flow(flow_in, fs.w, ftx, linear_tap(row, fs.sy, fs.h), 2.0, fs.fm, xc, W);
             return make_float2(0.f, 0.f);
         };
         const float bxx = border_factor(xc, W);
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(ACC ? 192 : 128) void k_farneback_iter(const float*
                 const int q = pb.t0 + b + d;           // (WM: integer-volume semantics, warped_value in fdn_device.h)
                 const bool pad = WM == 1 && (q < wm.pad_lo || q >= wm.pad_hi);
                 const float acc_old = ld_off<float>(acc, o * 4u);
-                const float acc_new = fold_warped<WM>(img1, H, W, xc, y, f, acc_old, weight, pad, wm.pad64, wm.lo, wm.hi, wm.fixed8 != 0);
+                const float acc_new = fold_warped<WM>(img1, H, W, xc, y, f, acc_old, weight, pad, wm.pad64, wm.lo, wm.hi, wm.fixed8 != 0, wm.model == 1);
                 if (owner) st_off(acc, o * 4u, acc_new);
             }
             lds_barrier_iter();
@@ -376,10 +376,10 @@ static int launch_iter_t(const float* Rstack, const float* stack, const float* f
 // coarser level's flow of that size.  acc != nullptr: this is the last iteration of the finest level: warp + accumulate
 // (flow_out may then be nullptr when nobody needs the flow).  flow_in and flow_out must be different buffers.
 int launch_farneback_iter(const float* Rstack, const float* stack, const float* flow_in, float* flow_out, float* acc,
-                          PairBatch pb, int H, int W, int winsize, double weight, hipStream_t st, int coarse_h, int coarse_w, const WarpMode& wm)
+                          PairBatch pb, int H, int W, int winsize, double weight, hipStream_t st, int coarse_h, int coarse_w, const WarpMode& wm, const FmaMode& fm)
 {
     if (pb.npairs <= 0) return 0;
-    FlowSource fs{coarse_h, coarse_w, coarse_h > 0 ? (double)coarse_w / W : 1.0, coarse_h > 0 ? (double)coarse_h / H : 1.0};
+    FlowSource fs{coarse_h, coarse_w, coarse_h > 0 ? (double)coarse_w / W : 1.0, coarse_h > 0 ? (double)coarse_h / H : 1.0, fm};
     const double scale = 1. / ((double)winsize * winsize);
     const int mh = winsize / 2;
     switch (mh) {   // compile-time windows for the usual sizes; anything else takes the runtime-width build

@@ -495,6 +495,7 @@ __global__ __launch_bounds__(256) void k_sweep_side(const float* __restrict__ st
     const size_t step_stride = (size_t)pb.npairs * HW;     // float2 elements between consecutive steps' flows
     const float2* fl = (const float2*)flows + (size_t)b * HW + o;
     const int dir = pb.d;                                   // -1: the back side, +1: the forward side
+    const bool unq = wm.model == 1 && !(MODE == 2 && wm.fixed8);     // the "remap_model" option (8-bit images keep their fixed-point table)
     for (int s0 = 0; s0 < nsteps; s0 += U) {
         float2 f[U];
         RemapTaps t[U];
@@ -507,19 +508,19 @@ __global__ __launch_bounds__(256) void k_sweep_side(const float* __restrict__ st
         for (int u = 0; u < U; u++) {
             const int s = s0 + u < nsteps ? s0 + u : nsteps - 1;
             const float* src = stack + (size_t)(pb.t0 + b + dir * (first_step + s + 1)) * HW;
-            remap_issue<true>(src, H, W, x, y, f[u], t[u]);
+            remap_issue<true>(src, H, W, x, y, f[u], t[u], unq);
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
             if (s0 + u < nsteps) {
                 if (MODE == 1) {          // float64 padded volume (seq on integer input)
                     const int q = pb.t0 + b + dir * (first_step + s0 + u + 1);
-                    a = (float)((double)a + remap_finish_f64(t[u], q < wm.pad_lo || q >= wm.pad_hi, wm.pad64) * sw.w[s0 + u]);
+                    a = (float)((double)a + remap_finish_f64(t[u], q < wm.pad_lo || q >= wm.pad_hi, wm.pad64, unq) * sw.w[s0 + u]);
                 } else if (MODE == 2) {   // integer neighbour image (par on integer input): saturate_cast<T>(float) = cvRound, clamped
-                    const float v = wm.fixed8 ? remap_finish_u8(t[u]) : fminf(fmaxf(rintf(remap_finish(t[u])), wm.lo), wm.hi);
+                    const float v = wm.fixed8 ? remap_finish_u8(t[u]) : fminf(fmaxf(rintf(remap_finish(t[u], unq)), wm.lo), wm.hi);
                     a = (float)((double)a + (double)v * sw.w[s0 + u]);
                 } else
-                    a = (float)((double)a + (double)remap_finish(t[u]) * sw.w[s0 + u]);
+                    a = (float)((double)a + (double)remap_finish(t[u], unq) * sw.w[s0 + u]);
             }
     }
     acc[o] = a;
@@ -549,18 +550,18 @@ void launch_sweep_side(const float* stack, const float* flows, float* acc, PairB
 }
 
 __global__ __launch_bounds__(256) void k_warp(const float* __restrict__ src, const float* __restrict__ flow_base,
-                                              float* __restrict__ dst, int H, int W)
+                                              float* __restrict__ dst, int H, int W, int model)
 {
     int x = blockIdx.x * 64 + (threadIdx.x & 63);
     int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     size_t o = (size_t)y * W + x;
-    dst[o] = remap_sample(src, H, W, x, y, ((const float2*)flow_base)[o]);
+    dst[o] = remap_sample(src, H, W, x, y, ((const float2*)flow_base)[o], model == 1);
 }
-void launch_warp(const float* src, const float* flow, float* dst, int H, int W, hipStream_t st)
+void launch_warp(const float* src, const float* flow, float* dst, int H, int W, hipStream_t st, int model)
 {
     dim3 grid((W + 63) / 64, (H + 3) / 4, 1);
-    hipLaunchKernelGGL(k_warp, grid, dim3(256), 0, st, src, flow, dst, H, W);
+    hipLaunchKernelGGL(k_warp, grid, dim3(256), 0, st, src, flow, dst, H, W, model);
 }
 
 __global__ __launch_bounds__(256) void k_warp_u8(const float* __restrict__ src, const float* __restrict__ flow_base,
@@ -581,18 +582,18 @@ void launch_warp_u8(const float* src, const float* flow, float* dst, int H, int 
 }
 
 __global__ __launch_bounds__(256) void k_warp_f64(const double* __restrict__ src, const float* __restrict__ flow_base,
-                                                  double* __restrict__ dst, int H, int W)
+                                                  double* __restrict__ dst, int H, int W, int model)
 {
     int x = blockIdx.x * 64 + (threadIdx.x & 63);
     int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     size_t o = (size_t)y * W + x;
-    dst[o] = remap_sample_f64(src, H, W, x, y, ((const float2*)flow_base)[o]);
+    dst[o] = remap_sample_f64(src, H, W, x, y, ((const float2*)flow_base)[o], model == 1);
 }
-void launch_warp_f64(const double* src, const float* flow, double* dst, int H, int W, hipStream_t st)
+void launch_warp_f64(const double* src, const float* flow, double* dst, int H, int W, hipStream_t st, int model)
 {
     dim3 grid((W + 63) / 64, (H + 3) / 4, 1);
-    hipLaunchKernelGGL(k_warp_f64, grid, dim3(256), 0, st, src, flow, dst, H, W);
+    hipLaunchKernelGGL(k_warp_f64, grid, dim3(256), 0, st, src, flow, dst, H, W, model);
 }
 
 __global__ __launch_bounds__(256) void k_axpy_slices(const float* __restrict__ stack, float* __restrict__ acc_base,
@@ -907,36 +908,42 @@ void launch_truncate_from_f32(const float* in, int depth, void* out, size_t coun
 // ---------------------------------------------------------------------------------
 // Pyramid pieces (levels > 0): cv::GaussianBlur with runtime taps, cv::resize
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_blur_h(const float* __restrict__ in, float* __restrict__ out, int H, int W, BlurTaps bt)
+// one pixel of the horizontal pass (RowFilter / SymmRowSmallFilter), the multiply-adds rounding as `fused` says
+static __device__ __forceinline__ float blur_row_at(const float* __restrict__ S, int x, int W, const BlurTaps& bt, bool fused)
+{
+    const int n = bt.n, c = n / 2;
+    float s0;
+    if (n == 3) {
+        s0 = madf(fused, S[reflect101(x - 1, W)] + S[reflect101(x + 1, W)], bt.k[2], S[x] * bt.k[1]);
+    } else if (n == 5) {
+        s0 = madf(fused, S[reflect101(x - 1, W)] + S[reflect101(x + 1, W)], bt.k[3], S[x] * bt.k[2]);
+        s0 = madf(fused, S[reflect101(x - 2, W)] + S[reflect101(x + 2, W)], bt.k[4], s0);
+    } else {
+        s0 = bt.k[0] * S[reflect101(x - c, W)];
+        for (int j = 1; j < n; j++) s0 = madf(fused, bt.k[j], S[reflect101(x - c + j, W)], s0);
+    }
+    return s0;
+}
+__global__ __launch_bounds__(256) void k_blur_h(const float* __restrict__ in, float* __restrict__ out, int H, int W, BlurTaps bt, FmaMode fm)
 {
     const size_t HW = (size_t)H * W;
     int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     const float* S = in + (size_t)blockIdx.z * HW + (size_t)y * W;
-    const int n = bt.n, c = n / 2;
-    float s0;
-    if (n == 3) {
-        s0 = S[x] * bt.k[1] + (S[reflect101(x - 1, W)] + S[reflect101(x + 1, W)]) * bt.k[2];
-    } else if (n == 5) {
-        s0 = S[x] * bt.k[2] + (S[reflect101(x - 1, W)] + S[reflect101(x + 1, W)]) * bt.k[3]
-             + (S[reflect101(x - 2, W)] + S[reflect101(x + 2, W)]) * bt.k[4];
-    } else {
-        s0 = bt.k[0] * S[reflect101(x - c, W)];
-        for (int j = 1; j < n; j++) s0 = s0 + bt.k[j] * S[reflect101(x - c + j, W)];
-    }
-    out[(size_t)blockIdx.z * HW + (size_t)y * W + x] = s0;
+    out[(size_t)blockIdx.z * HW + (size_t)y * W + x] = blur_row_at(S, x, W, bt, fma_at(fm, x, W));
 }
-__global__ __launch_bounds__(256) void k_blur_v(const float* __restrict__ in, float* __restrict__ out, int H, int W, BlurTaps bt)
+__global__ __launch_bounds__(256) void k_blur_v(const float* __restrict__ in, float* __restrict__ out, int H, int W, BlurTaps bt, FmaMode fm)
 {
     const size_t HW = (size_t)H * W;
     int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     const float* T = in + (size_t)blockIdx.z * HW;
     const int c = bt.n / 2;
+    const bool fused = fma_at(fm, x, W);
     float d = bt.k[c] * T[(size_t)y * W + x];
     for (int j = 1; j <= c; j++) {
         float sp = T[(size_t)reflect101(y + j, H) * W + x], sm = T[(size_t)reflect101(y - j, H) * W + x];
-        d = d + bt.k[c + j] * (sp + sm);
+        d = madf(fused, bt.k[c + j], sp + sm, d);
     }
     out[(size_t)blockIdx.z * HW + (size_t)y * W + x] = d;
 }
@@ -962,7 +969,7 @@ static __device__ __forceinline__ void sel_taps(int d, int n_src, double scale, 
 }
 
 __global__ __launch_bounds__(256) void k_blur_h_sel(const float* __restrict__ in, float* __restrict__ tmp, int H, int W, int dw,
-                                                    ResizeSel rs, BlurTaps bt)
+                                                    ResizeSel rs, BlurTaps bt, FmaMode fm)
 {
     const int j = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (j >= 2 * dw || y >= H) return;
@@ -970,22 +977,12 @@ __global__ __launch_bounds__(256) void k_blur_h_sel(const float* __restrict__ in
     sel_taps(j >> 1, W, rs.scale_x, rs.area, x0, x1, fx);
     const int x = (j & 1) ? x1 : x0;
     const float* S = in + (size_t)blockIdx.z * H * W + (size_t)y * W;
-    const int n = bt.n, c = n / 2;
-    float s0;
-    if (n == 3) {
-        s0 = S[x] * bt.k[1] + (S[reflect101(x - 1, W)] + S[reflect101(x + 1, W)]) * bt.k[2];
-    } else if (n == 5) {
-        s0 = S[x] * bt.k[2] + (S[reflect101(x - 1, W)] + S[reflect101(x + 1, W)]) * bt.k[3]
-             + (S[reflect101(x - 2, W)] + S[reflect101(x + 2, W)]) * bt.k[4];
-    } else {
-        s0 = bt.k[0] * S[reflect101(x - c, W)];
-        for (int q = 1; q < n; q++) s0 = s0 + bt.k[q] * S[reflect101(x - c + q, W)];
-    }
-    tmp[((size_t)blockIdx.z * H + y) * (2 * dw) + j] = s0;
+    // (the option goes by the pixel's column in the FULL image: cv::GaussianBlur filters whole rows)
+    tmp[((size_t)blockIdx.z * H + y) * (2 * dw) + j] = blur_row_at(S, x, W, bt, fma_at(fm, x, W));
 }
 
 __global__ __launch_bounds__(256) void k_blur_v_resize(const float* __restrict__ tmp, float* __restrict__ out, int H, int dh, int dw,
-                                                       int W, ResizeSel rs, BlurTaps bt)
+                                                       int W, ResizeSel rs, BlurTaps bt, FmaMode fm)
 {
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dx >= dw || dy >= dh) return;
@@ -994,6 +991,7 @@ __global__ __launch_bounds__(256) void k_blur_v_resize(const float* __restrict__
     sel_taps(dx, W, rs.scale_x, rs.area, xa, xb, fx);        // only the fraction is needed here
     const float* T = tmp + (size_t)blockIdx.z * H * (2 * dw) + 2 * dx;
     const int pitch = 2 * dw, c = bt.n / 2;
+    const bool fa = fma_at(fm, xa, W), fb = fma_at(fm, xb, W);      // the vertical pass, by the two source columns' places in the full row
     float v[2][2];
 #pragma unroll
     for (int r = 0; r < 2; r++) {
@@ -1003,8 +1001,8 @@ __global__ __launch_bounds__(256) void k_blur_v_resize(const float* __restrict__
         for (int q = 1; q <= c; q++) {
             const float2 sp = *(const float2*)(T + (size_t)reflect101(y + q, H) * pitch);
             const float2 sm = *(const float2*)(T + (size_t)reflect101(y - q, H) * pitch);
-            da = da + bt.k[c + q] * (sp.x + sm.x);
-            db = db + bt.k[c + q] * (sp.y + sm.y);
+            da = madf(fa, bt.k[c + q], sp.x + sm.x, da);
+            db = madf(fb, bt.k[c + q], sp.y + sm.y, db);
         }
         v[r][0] = da; v[r][1] = db;
     }
@@ -1017,35 +1015,35 @@ __global__ __launch_bounds__(256) void k_blur_v_resize(const float* __restrict__
         const float a1 = fx, a0 = 1.f - fx, b1 = fy, b0 = 1.f - fy;
         const float r0 = v[0][0] * a0 + v[0][1] * a1;
         const float r1 = v[1][0] * a0 + v[1][1] * a1;
-        res = r0 * b0 + r1 * b1;
+        res = madf(fma_at(fm, dx, dw), r0, b0, r1 * b1);             // VResizeLinear, by the place in the destination row
     }
     out[((size_t)blockIdx.z * dh + dy) * dw + dx] = res;
 }
 
 // small = resize(GaussianBlur(in, taps bt), (dw, dh), INTER_LINEAR) for nimg images; tmp: nimg * H * 2 dw floats
-void launch_blur_resize(const float* in, float* tmp, float* small, int nimg, int H, int W, int dh, int dw, const BlurTaps& bt, hipStream_t st)
+void launch_blur_resize(const float* in, float* tmp, float* small, int nimg, int H, int W, int dh, int dw, const BlurTaps& bt, hipStream_t st, const FmaMode& fm)
 {
     if (nimg <= 0) return;
     const double scale_x = (double)W / dw, scale_y = (double)H / dh;
     const int isx = (int)scale_x, isy = (int)scale_y;
     const bool integer = fabs(scale_x - isx) < 2.220446049250313e-16 && fabs(scale_y - isy) < 2.220446049250313e-16;
     ResizeSel rs{integer && isx == 2 && isy == 2 ? 1 : 0, scale_x, scale_y};
-    hipLaunchKernelGGL(k_blur_h_sel, dim3((2 * dw + 63) / 64, (H + 3) / 4, nimg), dim3(256), 0, st, in, tmp, H, W, dw, rs, bt);
-    hipLaunchKernelGGL(k_blur_v_resize, dim3((dw + 63) / 64, (dh + 3) / 4, nimg), dim3(256), 0, st, tmp, small, H, dh, dw, W, rs, bt);
+    hipLaunchKernelGGL(k_blur_h_sel, dim3((2 * dw + 63) / 64, (H + 3) / 4, nimg), dim3(256), 0, st, in, tmp, H, W, dw, rs, bt, fm);
+    hipLaunchKernelGGL(k_blur_v_resize, dim3((dw + 63) / 64, (dh + 3) / 4, nimg), dim3(256), 0, st, tmp, small, H, dh, dw, W, rs, bt, fm);
 }
 
-void launch_gaussian_blur(const float* in, float* tmp, float* out, int nimg, int H, int W, const BlurTaps& bt, hipStream_t st)
+void launch_gaussian_blur(const float* in, float* tmp, float* out, int nimg, int H, int W, const BlurTaps& bt, hipStream_t st, const FmaMode& fm)
 {
     if (nimg <= 0) return;
     dim3 grid((W + 63) / 64, (H + 3) / 4, nimg);
-    hipLaunchKernelGGL(k_blur_h, grid, dim3(256), 0, st, in, tmp, H, W, bt);
-    hipLaunchKernelGGL(k_blur_v, grid, dim3(256), 0, st, tmp, out, H, W, bt);
+    hipLaunchKernelGGL(k_blur_h, grid, dim3(256), 0, st, in, tmp, H, W, bt, fm);
+    hipLaunchKernelGGL(k_blur_v, grid, dim3(256), 0, st, tmp, out, H, W, bt, fm);
 }
 
 // INTER_LINEAR (HResizeLinear then VResizeLinear, f32 coefficients)
 template <int CN>
 __global__ __launch_bounds__(256) void k_resize_linear(const float* __restrict__ in, int sh, int sw, float* __restrict__ out,
-                                                       int dh, int dw, double scale_x, double scale_y, int apply_ps, double ps)
+                                                       int dh, int dw, double scale_x, double scale_y, int apply_ps, double ps, FmaMode fm)
 {
     int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dx >= dw || dy >= dh) return;
@@ -1067,7 +1065,7 @@ __global__ __launch_bounds__(256) void k_resize_linear(const float* __restrict__
     for (int ch = 0; ch < CN; ch++) {
         float r0 = S0[sx * CN + ch] * a0 + S0[sx1 * CN + ch] * a1;
         float r1 = S1[sx * CN + ch] * a0 + S1[sx1 * CN + ch] * a1;
-        float v = r0 * b0 + r1 * b1;
+        float v = madf(fma_at(fm, dx * CN + ch, dw * CN), r0, b0, r1 * b1);
         if (apply_ps) v = (float)((double)v * ps);
         dst[((size_t)dy * dw + dx) * CN + ch] = v;
     }
@@ -1182,7 +1180,7 @@ bool resize_needs_tables(int sh, int sw, int dh, int dw, int interp)
 }
 
 void resize_images(const float* in, int sh, int sw, float* out, int dh, int dw, int cn, int nimg, int interp,
-                   bool apply_ps, double ps, hipStream_t st)
+                   bool apply_ps, double ps, hipStream_t st, const FmaMode& fm)
 {
     if (nimg <= 0) return;
     dim3 grid((dw + 63) / 64, (dh + 3) / 4, nimg);
@@ -1200,8 +1198,8 @@ void resize_images(const float* in, int sh, int sw, float* out, int dh, int dw, 
         if (cn == 1) hipLaunchKernelGGL(k_resize_area_int<1>, grid, dim3(256), 0, st, in, sh, sw, out, dh, dw, isx, isy, (int)apply_ps, ps);
         else hipLaunchKernelGGL(k_resize_area_int<2>, grid, dim3(256), 0, st, in, sh, sw, out, dh, dw, isx, isy, (int)apply_ps, ps);
     } else {
-        if (cn == 1) hipLaunchKernelGGL(k_resize_linear<1>, grid, dim3(256), 0, st, in, sh, sw, out, dh, dw, scale_x, scale_y, (int)apply_ps, ps);
-        else hipLaunchKernelGGL(k_resize_linear<2>, grid, dim3(256), 0, st, in, sh, sw, out, dh, dw, scale_x, scale_y, (int)apply_ps, ps);
+        if (cn == 1) hipLaunchKernelGGL(k_resize_linear<1>, grid, dim3(256), 0, st, in, sh, sw, out, dh, dw, scale_x, scale_y, (int)apply_ps, ps, fm);
+        else hipLaunchKernelGGL(k_resize_linear<2>, grid, dim3(256), 0, st, in, sh, sw, out, dh, dw, scale_x, scale_y, (int)apply_ps, ps, fm);
     }
 }
 

@@ -112,7 +112,8 @@ int fdn_workspace_bytes(fdn_handle h, size_t* bytes_out);
 int fdn_mem_info(fdn_handle h, size_t* free_out, size_t* total_out);
 
 /* Switches of a live handle (tests and experiments; fdn_create reads the same from the environment:
- * FDN_STRICT_ORDER, FDN_PATH / FDN_FORCE_STAGED, FDN_FUSED_OCC, FDN_LDS_PAD, FDN_SUB_BATCHES).  Every path gives the same
+ * FDN_STRICT_ORDER, FDN_PATH / FDN_FORCE_STAGED, FDN_FUSED_OCC, FDN_LDS_PAD, FDN_SUB_BATCHES, FDN_OPENCV_FMA,
+ * FDN_OPENCV_FMA_LANES, FDN_REMAP_MODEL).  Every path gives the same
  * bits except strict_order:
  *   "strict_order" 0/1  OpenCV's serial f64 running sum along x in FarnebackUpdateFlow_Blur instead of the
  *                       direct window sum (about 20x slower; errors out, never falls back, when a row does
@@ -129,6 +130,17 @@ int fdn_mem_info(fdn_handle h, size_t* free_out, size_t* total_out);
  *                  chain of both sides on a stream of its own -- the tail of one half's launch is filled by the other
  *                  half's work (the reference's remainder round, par:194-206, keeps its workers busy the same way).
  *                  Automatic: two when a launch of the pass, at any pyramid level, is under four rounds of slots.
+ *   "opencv_fma"   how the multiply-adds of cv::GaussianBlur's two passes and of cv::resize's vertical pass round -- pyramid levels
+ *                  >= 1 only: 0 (default) two roundings, the reading of OpenCV's scalar code; 1 fused everywhere; 2 fused on the
+ *                  vector body of a row, its first (width / lanes) * lanes elements, and not on the tail ("opencv_fma_lanes", 8 =
+ *                  AVX2).  opencv-python is unpinned in the reference and absent here: which of these a given wheel
+ *                  does is unknown, and at levels > 0 it moves results by up to 2e-3 -- the day a cv2 is at hand the matching
+ *                  reading is a switch, on the oracle (fdo_set_fma) and here, bit-equal to each other in every mode.
+ *   "remap_model"  cv2.remap on a float map: 0 (default) the classic path, coordinates rounded to 1/32 pixel and weights from
+ *                  the 32 x 32 table; 1 unquantised float32 bilinear interpolation (two lerps), a model of the reworked remap
+ *                  of newer OpenCV releases; 8-bit images keep their fixed-point table either way.  tests/test_cv2_pin.py tells
+ *                  the two apart on a real cv2.
+ * The first group changes speed only (same bits); "opencv_fma" and "remap_model" change results: they select which cv2 is matched.
  * No counterpart in the reference (cv2 has no such switches). */
 int fdn_set_option(fdn_handle h, const char* name, long value);
 /* Reads an option back; also the read-only "last_sub_batches" (what the last sweep ran with) and "compute_units". */
@@ -146,7 +158,16 @@ int fdn_memcpy2d_h2d(fdn_handle h, void* dst_dev, size_t dst_pitch, const void* 
                      size_t width_bytes, size_t height);
 int fdn_memcpy2d_d2h(fdn_handle h, void* dst_host, size_t dst_pitch, const void* src_dev, size_t src_pitch,
                      size_t width_bytes, size_t height);
-/* page-lock / release a host buffer of the caller (hipHostRegister): copies from and to it then run at PCIe speed */
+/* How host memory travels.  fdn_memcpy_h2d / _d2h / fdn_memcpy2d_* and the host-pointer entry points (fdn_filter_3d, ...)
+ * never hand PAGEABLE memory to the copy engines: memory that was page-locked through fdn_host_register moves in one DMA;
+ * a contiguous block of 8 MB or more is page-locked by the library for the duration of the call; everything else goes
+ * through a page-locked bounce buffer of the handle (one host memcpy more).  The reason is in the HIP runtime: a copy of
+ * pageable memory above about 1 MB is page-locked by the runtime on the fly, that registration outlives the call, and a
+ * later copy that meets one whose pages the application has freed in the meantime ends in a GPU memory fault and an abort
+ * of the process (caught in round 6; profiles/history/NOTES_r06.md, section 2). */
+/* page-lock / release a host buffer of the caller (hipHostRegister): copies from and to it then run at PCIe speed.
+ * Release it BEFORE the memory is freed.  A registration belongs to the process: fdn_host_unregister accepts any handle,
+ * and NULL. */
 int fdn_host_register(fdn_handle h, void* ptr, size_t bytes);
 int fdn_host_unregister(fdn_handle h, void* ptr);
 

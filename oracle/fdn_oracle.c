@@ -140,13 +140,35 @@ static void cv_gaussian_kernel_f32(int n, double sigma, float* k)
  * Symmetric small-kernel forms for n==3 / n==5 (SymmRowSmallFilter), left-to-right
  * tap accumulation otherwise (RowFilter); vertical pass is SymmColumnFilter:
  * s = k[c]*S[c] ; s += k[c+j]*(S[c+j] + S[c-j]). */
-/* Sensitivity switch (tools/fma_sensitivity.py), NOT a claim about any particular cv2 build: stock x86 wheels run
- * these filters through SIMD code whose v_muladd becomes a fused multiply-add on AVX2/FMA3 machines (and plain C on
- * the row tails); with fdo_set_fma(1) every tap of the blur and the vertical resize pass is fused, to measure how far
- * that can move a result.  At levels = 0 the taps are powers of two and fusing changes nothing. */
-static int g_fma = 0;
-FDO_EXPORT void fdo_set_fma(int on) { g_fma = on; }
-static inline float mad(float a, float b, float c) { return g_fma ? fmaf(a, b, c) : a * b + c; }
+/* How the multiply-adds of the blur's two passes and of the vertical resize pass round -- NOT a claim about any particular
+ * cv2 build: stock x86 wheels run these filters through SIMD code whose v_muladd becomes a fused multiply-add on AVX2 / FMA3
+ * machines, and plain C on the row tails.  The same three readings as the product's "opencv_fma" option
+ * (flowdenoising_amd/csrc/fdn_internal.h, FmaMode), so that the day a cv2 is at hand the matching one is a switch on both sides:
+ *   0  two roundings everywhere (the default: OpenCV's scalar code)
+ *   1  fused everywhere
+ *   2  fused on the vector body of a row -- its first (width / lanes) * lanes elements (lanes: 8 for AVX2) --, two roundings on
+ *      the tail.  `i` is the element's index in its row of `width` elements (channels interleaved).
+ * At levels = 0 the only blur taps are powers of two and fusing changes nothing. */
+static int g_fma = 0, g_fma_lanes = 8;
+FDO_EXPORT void fdo_set_fma(int mode) { g_fma = mode; }
+FDO_EXPORT void fdo_set_fma_lanes(int lanes) { g_fma_lanes = lanes > 0 ? lanes : 8; }
+static inline float mad_at(int i, int width, float a, float b, float c)
+{
+    const int fused = g_fma == 1 || (g_fma == 2 && i < width / g_fma_lanes * g_fma_lanes);
+    return fused ? fmaf(a, b, c) : a * b + c;
+}
+/* Which cv2.remap a warp follows (the product's "remap_model" option): 0 = the classic path (coordinates rounded to 1/32 pixel,
+ * weights from the 32 x 32 table), 1 = unquantised float32 bilinear interpolation at the map position -- a model of the
+ * reworked float-map remap newer OpenCV releases are reported to ship (tests/test_cv2_pin.py classifies a real cv2 between
+ * the two).  8-bit images keep their fixed-point table in either model. */
+static int g_remap_model = 0;
+FDO_EXPORT void fdo_set_remap_model(int model) { g_remap_model = model; }
+static inline int floor_index(float v, float* frac)
+{
+    const float fl = floorf(v);
+    *frac = v - fl;
+    return (int)fminf(fmaxf(fl, -32768.f), 32767.f);
+}
 
 static void cv_gaussian_blur_f32(const float* src, float* dst, int H, int W, int n, double sigma)
 {
@@ -160,13 +182,13 @@ static void cv_gaussian_blur_f32(const float* src, float* dst, int H, int W, int
         for (int x = 0; x < W; x++) {
             float s0;
             if (n == 3) {
-                s0 = mad(S[reflect101(x - 1, W)] + S[reflect101(x + 1, W)], k[2], S[x] * k[1]);
+                s0 = mad_at(x, W, S[reflect101(x - 1, W)] + S[reflect101(x + 1, W)], k[2], S[x] * k[1]);
             } else if (n == 5) {
-                s0 = mad(S[reflect101(x - 1, W)] + S[reflect101(x + 1, W)], k[3], S[x] * k[2]);
-                s0 = mad(S[reflect101(x - 2, W)] + S[reflect101(x + 2, W)], k[4], s0);
+                s0 = mad_at(x, W, S[reflect101(x - 1, W)] + S[reflect101(x + 1, W)], k[3], S[x] * k[2]);
+                s0 = mad_at(x, W, S[reflect101(x - 2, W)] + S[reflect101(x + 2, W)], k[4], s0);
             } else {
                 s0 = k[0] * S[reflect101(x - c, W)];
-                for (int j = 1; j < n; j++) s0 = mad(k[j], S[reflect101(x - c + j, W)], s0);
+                for (int j = 1; j < n; j++) s0 = mad_at(x, W, k[j], S[reflect101(x - c + j, W)], s0);
             }
             T[x] = s0;
         }
@@ -179,7 +201,7 @@ static void cv_gaussian_blur_f32(const float* src, float* dst, int H, int W, int
             const float* Sp = tmp + (size_t)reflect101(y + j, H) * W;
             const float* Sm = tmp + (size_t)reflect101(y - j, H) * W;
             float kj = k[c + j];
-            for (int x = 0; x < W; x++) D[x] = mad(kj, Sp[x] + Sm[x], D[x]);
+            for (int x = 0; x < W; x++) D[x] = mad_at(x, W, kj, Sp[x] + Sm[x], D[x]);
         }
     }
     free(tmp);
@@ -223,7 +245,7 @@ static void cv_resize_linear_f32(const float* src, int sh, int sw, float* dst, i
         }
         float b1 = fy, b0 = 1.f - fy;
         float* D = dst + (size_t)dy * dw * cn;
-        for (int i = 0; i < dw * cn; i++) D[i] = mad(r0[i], b0, r1[i] * b1);
+        for (int i = 0; i < dw * cn; i++) D[i] = mad_at(i, dw * cn, r0[i], b0, r1[i] * b1);
     }
     free(r0); free(r1); free(xofs); free(xa);
 }
@@ -854,6 +876,15 @@ FDO_EXPORT void fdo_remap_linear_replicate(const float* src, int H, int W, const
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) {
             const float* mp = mapxy + ((size_t)y * W + x) * 2;
+            if (g_remap_model == 1) {       /* unquantised: two float32 lerps, along x in both rows, then along y */
+                float fx, fy;
+                const int ix = floor_index(mp[0], &fx), iy = floor_index(mp[1], &fy);
+                const int x0 = clampi(ix, 0, W - 1), x1 = clampi(ix + 1, 0, W - 1), y0 = clampi(iy, 0, H - 1), y1 = clampi(iy + 1, 0, H - 1);
+                const float top = src[(size_t)y0 * W + x0] * (1.f - fx) + src[(size_t)y0 * W + x1] * fx;
+                const float bot = src[(size_t)y1 * W + x0] * (1.f - fx) + src[(size_t)y1 * W + x1] * fx;
+                dst[(size_t)y * W + x] = top * (1.f - fy) + bot * fy;
+                continue;
+            }
             int sx = cv_round_f(mp[0] * 32), sy = cv_round_f(mp[1] * 32);
             int ax = sx & 31, ay = sy & 31;
             int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);
@@ -999,6 +1030,20 @@ static void warp_slice_f64(const float* reference, int is_pad, const float* flow
         for (int x = 0; x < W; x++) {
             size_t i = ((size_t)y * W + x) * 2;
             float mx = (float)((double)flow[i] + (double)x), my = (float)((double)flow[i + 1] + (double)y);
+            if (g_remap_model == 1) {       /* unquantised, on a CV_64F image: values and sums in double, the float32 fractions widened */
+                float fx, fy;
+                const int ix = floor_index(mx, &fx), iy = floor_index(my, &fy);
+                const int x0 = clampi(ix, 0, W - 1), x1 = clampi(ix + 1, 0, W - 1), y0 = clampi(iy, 0, H - 1), y1 = clampi(iy + 1, 0, H - 1);
+                double v0, v1, v2, v3;
+                if (is_pad) v0 = v1 = v2 = v3 = g_mean64;
+                else {
+                    v0 = reference[(size_t)y0 * W + x0]; v1 = reference[(size_t)y0 * W + x1];
+                    v2 = reference[(size_t)y1 * W + x0]; v3 = reference[(size_t)y1 * W + x1];
+                }
+                const double top = v0 * (double)(1.f - fx) + v1 * (double)fx, bot = v2 * (double)(1.f - fx) + v3 * (double)fx;
+                dst[(size_t)y * W + x] = top * (double)(1.f - fy) + bot * (double)fy;
+                continue;
+            }
             int sx = cv_round_f(mx * 32), sy = cv_round_f(my * 32);
             int ax = sx & 31, ay = sy & 31;
             int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);
@@ -1023,6 +1068,15 @@ FDO_EXPORT void fdo_remap_linear_replicate_f64(const double* src, int H, int W, 
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) {
             const float* mp = mapxy + ((size_t)y * W + x) * 2;
+            if (g_remap_model == 1) {
+                float fx, fy;
+                const int ix = floor_index(mp[0], &fx), iy = floor_index(mp[1], &fy);
+                const int x0 = clampi(ix, 0, W - 1), x1 = clampi(ix + 1, 0, W - 1), y0 = clampi(iy, 0, H - 1), y1 = clampi(iy + 1, 0, H - 1);
+                const double top = src[(size_t)y0 * W + x0] * (double)(1.f - fx) + src[(size_t)y0 * W + x1] * (double)fx;
+                const double bot = src[(size_t)y1 * W + x0] * (double)(1.f - fx) + src[(size_t)y1 * W + x1] * (double)fx;
+                dst[(size_t)y * W + x] = top * (double)(1.f - fy) + bot * (double)fy;
+                continue;
+            }
             int sx = cv_round_f(mp[0] * 32), sy = cv_round_f(mp[1] * 32);
             int ax = sx & 31, ay = sy & 31;
             int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);

@@ -61,9 +61,18 @@ def lib():
     return _lib
 
 
-def set_fma(on):
-    """Sensitivity switch: fuse every multiply-add of the pyramid blur and of the vertical resize pass (see fdn_oracle.c)."""
-    lib().fdo_set_fma(ctypes.c_int(int(bool(on))))
+def set_fma(mode, lanes=8):
+    """How the multiply-adds of the pyramid blur and of the vertical resize pass round (fdn_oracle.c; the product's "opencv_fma"
+    option): 0 = two roundings (default), 1 = fused everywhere, 2 = fused on the first (width // lanes) * lanes elements of a row
+    and two roundings on its tail."""
+    lib().fdo_set_fma(ctypes.c_int(int(mode)))
+    lib().fdo_set_fma_lanes(ctypes.c_int(int(lanes)))
+
+
+def set_remap_model(model):
+    """Which cv2.remap the warps follow (the product's "remap_model" option): 0 = the classic 1/32-pixel table (default), 1 =
+    unquantised float32 bilinear."""
+    lib().fdo_set_remap_model(ctypes.c_int(int(model)))
 
 
 def OF_filter_integer_input(vol, kernel, l, w, nthreads=1, use_of=True):

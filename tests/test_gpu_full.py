@@ -1029,3 +1029,160 @@ def test_sub_batches_on_two_streams_give_the_same_bits(fdn, case):
         if case.get("limit"):
             h.set_workspace_limit(0)
     assert np.array_equal(outs[1], outs[2]) and np.array_equal(outs[1], outs[0])
+
+
+def test_handles_used_from_threads_in_this_process(fdn, oracle):
+    """Multi-threaded use of the library INSIDE the long-lived test process (most multi-threaded GPU tests run in processes
+    of their own, conftest.run_in_fresh_process): four threads share the process-wide handle through the pair operators (the
+    C ABI takes the handle's lock), three more own a handle each -- created in the thread, closed by the main thread, the
+    out-of-core mode's pattern -- and run sweeps at the same time; then the out-of-core mode itself; then an ordinary
+    single-threaded filter of a fresh 1.1 MB volume, the kind of call round 5's sessions aborted in (NOTES_r06.md section 2).
+    Everything must equal the single-threaded results bit for bit."""
+    import threading
+    from flowdenoising_amd import _lib, streaming
+    from flowdenoising_amd.operators import _params
+    vol = _vol((12, 96, 160), seed=5)
+    k = fdn.get_gaussian_kernel(1.0)
+    r = k.size // 2
+    params = _params(0, 5)
+    S, H, W = vol.shape[0] - 2 * r, vol.shape[1], vol.shape[2]
+    want_flow = [fdn.get_flow(vol[i + 1], vol[i], 0, 5, np.zeros((H, W, 2), np.float32)) for i in range(4)]
+    want_warp = [fdn.warp_slice(vol[i + 1], want_flow[i]) for i in range(4)]
+    want_sweep = fdn.OF_filter_along_Z(vol, k, 0, 5, vol.mean())
+    got, made, errors = {}, [], []
+
+    def pair_user(i):
+        try:
+            for _ in range(5):
+                f = fdn.get_flow(vol[i + 1], vol[i], 0, 5, np.zeros((H, W, 2), np.float32))
+                got[("flow", i)], got[("warp", i)] = f, fdn.warp_slice(vol[i + 1], f)
+        except BaseException as e:      # noqa: BLE001
+            errors.append(e)
+
+    def handle_owner(i):
+        try:
+            h = _lib.Handle(0)
+            made.append(h)
+            d_stack, d_out = h.malloc(vol.nbytes), h.malloc(S * H * W * 4)
+            for _ in range(3):
+                h.h2d(d_stack, vol)
+                h.sweep_stack_dev(d_stack, d_out, S, H, W, k, params)
+                out = np.empty((S, H, W), np.float32)
+                h.d2h(out, d_out)
+            h.free(d_stack)
+            h.free(d_out)
+            got[("sweep", i)] = out
+        except BaseException as e:      # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=pair_user, args=(i,)) for i in range(4)] + [threading.Thread(target=handle_owner, args=(i,)) for i in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for h in made:
+        h.close()
+    assert not errors, errors
+    for i in range(4):
+        assert np.array_equal(got[("flow", i)], want_flow[i]) and np.array_equal(got[("warp", i)], want_warp[i])
+    for i in range(3):
+        assert np.array_equal(got[("sweep", i)], want_sweep[r:r + S])
+    streamed = streaming.filter_streamed(vol, [k, k, None], 0, 5, chunk_slices=3)
+    assert np.array_equal(streamed, fdn.OF_filter(vol, [k, k, None], 0, 5))
+    fresh = _vol((7, 130, 300), seed=33)
+    out = fdn.OF_filter(fresh, [k, None, k], 0, 5)
+    assert np.array_equal(out, oracle.OF_filter(fresh, [k, None, k], 0, 5, nthreads=8))
+
+
+# ---- the two cv2 unknowns as product options (DESIGN.md 5): HIP and oracle agree bit for bit in every setting -----------------
+@pytest.mark.parametrize("mode,lanes", [(1, 8), (2, 8), (2, 4), (2, 16)])
+@pytest.mark.parametrize("w,path", [(5, 0), (15, 0), (7, 1)])
+def test_opencv_fma_modes_match_the_oracle(fdn, oracle, mode, lanes, w, path):
+    """fdn_set_option("opencv_fma", mode) / fdo_set_fma(mode): every multiply-add of the pyramid's blur and vertical resize
+    fused (1) or fused on the vector body of a row only (2, with the lane count) -- on the 3-iteration kernel (w = 5), the
+    one-iteration kernel (w = 15) and the per-stage kernels (path 1), Z and X passes of a volume whose pyramid rows are not
+    multiples of the lane counts.  The result differs from mode 0 and equals the oracle in the same mode."""
+    from flowdenoising_amd.operators import handle
+    vol = _vol((6, 70, 150), seed=17)
+    ks = [fdn.get_gaussian_kernel(1.0), None, fdn.get_gaussian_kernel(0.5)]
+    h = handle()
+    try:
+        h.set_option("path", path)
+        plain = fdn.OF_filter(vol, ks, 2, w)
+        h.set_option("opencv_fma", mode)
+        h.set_option("opencv_fma_lanes", lanes)
+        assert (h.get_option("opencv_fma"), h.get_option("opencv_fma_lanes")) == (mode, lanes)
+        got = fdn.OF_filter(vol, ks, 2, w)
+        level0 = fdn.OF_filter(vol, ks, 0, w)
+    finally:
+        h.set_option("opencv_fma", 0)
+        h.set_option("opencv_fma_lanes", 8)
+        h.set_option("path", 0)
+    try:
+        oracle.set_fma(mode, lanes)
+        want = oracle.OF_filter(vol, ks, 2, w, nthreads=8)
+    finally:
+        oracle.set_fma(0)
+    assert np.array_equal(got, want), rel_err(got, want)
+    assert not np.array_equal(got, plain) and rel_err(got, plain) < 5e-2
+    assert np.array_equal(level0, fdn.OF_filter(vol, ks, 0, w))                       # no pyramid: nothing to fuse
+
+
+@pytest.mark.parametrize("case", [
+    dict(l=0, w=5, border=0), dict(l=2, w=5, border=1), dict(l=1, w=15, border=0), dict(l=0, w=5, border=0, path=1),
+    dict(l=0, w=5, border=0, dtype=np.int16), dict(l=1, w=5, border=1, dtype=np.int16), dict(l=0, w=5, border=1, dtype=np.uint8),
+])
+def test_remap_model_matches_the_oracle(fdn, oracle, case):
+    """fdn_set_option("remap_model", 1) / fdo_set_remap_model(1): every warp of a sweep as unquantised float32 bilinear
+    interpolation instead of cv2's classic 1/32-pixel table -- in the Farneback kernels' final stage, in k_sweep_side (path 1)
+    and in the integer-volume semantics (float64 padded volume: doubles; 16-bit images: rounded; 8-bit: fixed point as before)."""
+    from flowdenoising_amd.operators import handle
+    vol = _vol((8, 48, 76), seed=23)
+    dt = case.get("dtype")
+    if dt is not None:
+        top = 255 if dt is np.uint8 else 3000
+        vol = np.round((vol - vol.min()) * (top / (vol.max() - vol.min())) - (0 if dt is np.uint8 else 700)).astype(dt)
+    ks = [fdn.get_gaussian_kernel(1.0), fdn.get_gaussian_kernel(0.5), fdn.get_gaussian_kernel(1.0)]
+    h = handle()
+    try:
+        h.set_option("path", case.get("path", 0))
+        classic = fdn.OF_filter(vol, ks, case["l"], case["w"], border_mode=case["border"])
+        h.set_option("remap_model", 1)
+        got = fdn.OF_filter(vol, ks, case["l"], case["w"], border_mode=case["border"])
+    finally:
+        h.set_option("remap_model", 0)
+        h.set_option("path", 0)
+    try:
+        oracle.set_remap_model(1)
+        if dt is None:
+            want = oracle.OF_filter(vol, ks, case["l"], case["w"], border_mode=case["border"], nthreads=8)
+        elif case["border"] == 0:
+            want = oracle.OF_filter_integer_input(vol, ks, case["l"], case["w"], nthreads=8)
+        else:
+            want = oracle.filter_par_integer_input(vol, ks, case["l"], case["w"], nthreads=8)
+    finally:
+        oracle.set_remap_model(0)
+    assert np.array_equal(got, np.asarray(want, dtype=got.dtype)), rel_err(got, want)
+    if dt is not np.uint8:
+        assert not np.array_equal(got, classic)
+    else:
+        assert np.array_equal(got, classic)                          # 8-bit images: the fixed-point table in either model
+
+
+def test_remap_model_on_the_pair_operators(fdn, oracle):
+    from flowdenoising_amd.operators import handle
+    rng = np.random.default_rng(9)
+    ref = (rng.standard_normal((40, 44)) * 100).astype(np.float32)
+    flow = (rng.standard_normal((40, 44, 2)) * 1.3).astype(np.float32)
+    m = np.stack([(flow[..., 0].astype(np.float64) + np.arange(44)[None, :]).astype(np.float32),
+                  (flow[..., 1].astype(np.float64) + np.arange(40)[:, None]).astype(np.float32)], axis=-1)
+    h = handle()
+    try:
+        h.set_option("remap_model", 1)
+        oracle.set_remap_model(1)
+        for img in (ref, ref.astype(np.float64), np.round(ref).astype(np.int16), np.clip(np.round(ref + 128), 0, 255).astype(np.uint8)):
+            got = fdn.warp_slice(img, flow)
+            assert got.dtype == img.dtype and np.array_equal(got, oracle.remap_any(img, m)), img.dtype
+    finally:
+        h.set_option("remap_model", 0)
+        oracle.set_remap_model(0)

@@ -247,3 +247,63 @@ def test_integer_volume_known_answers(oracle):
     np.testing.assert_allclose(out, 1000.0, rtol=1e-6)
     par = oracle.filter_par_integer_input(vol, ks, 0, 5)
     assert np.array_equal(par, np.trunc(par)) and np.all((par == 1000) | (par == 999))
+
+
+def test_fma_modes_of_the_pyramid(oracle):
+    """fdo_set_fma (the product's "opencv_fma" option): mode 2 is mode 0 when a row holds less than one vector, mode 1 when
+    every element is in the vector body; on rows that are not a multiple of the lane count it is neither; at levels = 0
+    (blur taps 1/4, 1/2, 1/4) no mode changes anything."""
+    rng = np.random.default_rng(3)
+    a = (rng.standard_normal((70, 150)) * 50).astype(np.float32)      # levels: 35 x 75, then 18 x 38 (both with row tails at 8 lanes)
+    b = (np.roll(a, 1, axis=1) + rng.standard_normal(a.shape).astype(np.float32)).astype(np.float32)
+    f0 = np.zeros(a.shape + (2,), np.float32)
+    got = {}
+    try:
+        for key, (mode, lanes) in {"plain": (0, 8), "fused": (1, 8), "body8": (2, 8), "body1": (2, 1), "body4096": (2, 4096)}.items():
+            oracle.set_fma(mode, lanes)
+            got[key] = oracle.get_flow(b, a, 2, 5, f0.copy())
+            got[key + "_l0"] = oracle.get_flow(b, a, 0, 5, f0.copy())
+    finally:
+        oracle.set_fma(0)
+    assert np.array_equal(got["body1"], got["fused"]) and np.array_equal(got["body4096"], got["plain"])
+    assert not np.array_equal(got["fused"], got["plain"])
+    assert not np.array_equal(got["body8"], got["plain"]) and not np.array_equal(got["body8"], got["fused"])
+    assert all(np.array_equal(got[k + "_l0"], got["plain_l0"]) for k in ("fused", "body8", "body1"))
+    assert np.abs(got["fused"] - got["plain"]).max() < 1e-2            # a last-bit effect amplified by the solve, not another algorithm
+
+
+def test_remap_model_switch(oracle):
+    """fdo_set_remap_model (the product's "remap_model" option): model 1 is plain float32 bilinear interpolation at the map
+    position -- two lerps, no 1/32-pixel table -- on float32, float64 and 16-bit images; 8-bit images keep their fixed-point table."""
+    rng = np.random.default_rng(4)
+    H, W = 37, 53
+    src = (rng.standard_normal((H, W)) * 100).astype(np.float32)
+    flow = (rng.standard_normal((H, W, 2)) * 1.7).astype(np.float32)
+    flow[0, 0] = (-5.0, -7.0)
+    flow[-1, -1] = (9.0, 3.0)                                           # clamped taps (BORDER_REPLICATE)
+    mx = (flow[..., 0].astype(np.float64) + np.arange(W)[None, :]).astype(np.float32)
+    my = (flow[..., 1].astype(np.float64) + np.arange(H)[:, None]).astype(np.float32)
+    m = np.stack([mx, my], axis=-1)
+    x0, y0 = np.floor(mx), np.floor(my)
+    fx, fy = (mx - x0).astype(np.float32), (my - y0).astype(np.float32)
+    xa, xb = np.clip(x0.astype(int), 0, W - 1), np.clip(x0.astype(int) + 1, 0, W - 1)
+    ya, yb = np.clip(y0.astype(int), 0, H - 1), np.clip(y0.astype(int) + 1, 0, H - 1)
+    one = np.float32(1)
+
+    def lerp(s, dt):
+        s = s.astype(dt)
+        wx0, wx1, wy0, wy1 = (one - fx).astype(dt), fx.astype(dt), (one - fy).astype(dt), fy.astype(dt)
+        return (s[ya, xa] * wx0 + s[ya, xb] * wx1) * wy0 + (s[yb, xa] * wx0 + s[yb, xb] * wx1) * wy1
+    classic = oracle.warp_slice(src, flow)
+    try:
+        oracle.set_remap_model(1)
+        assert np.array_equal(oracle.warp_slice(src, flow), lerp(src, np.float32))
+        assert np.array_equal(oracle.remap_any(src.astype(np.float64), m), lerp(src, np.float64))
+        i16 = np.round(src).astype(np.int16)
+        assert np.array_equal(oracle.remap_any(i16, m), np.clip(np.rint(lerp(i16, np.float32)), -32768, 32767).astype(np.int16))
+        u8 = np.clip(np.round(src + 128), 0, 255).astype(np.uint8)
+        unq_u8 = oracle.remap_any(u8, m)
+    finally:
+        oracle.set_remap_model(0)
+    assert np.array_equal(unq_u8, oracle.remap_any(u8, m))              # fixed point either way
+    assert not np.array_equal(classic, lerp(src, np.float32)) and np.abs(classic - lerp(src, np.float32)).max() < 0.05 * np.abs(src).max()
