@@ -732,6 +732,9 @@ static int pyramid_step_fused(fdn_ctx* h, const std::vector<PyrLevel>& lv, const
 // Which kernels a sweep runs on: 0 = the 3-iteration fused kernel, 1 = the one-iteration kernel, 2 = one kernel per stage
 static int sweep_path(const fdn_ctx* h, const fdn_sweep_params* p, const std::vector<PyrLevel>& lv, int H, int W)
 {
+    // the unquantised remap model on an integer volume's own semantics: the per-stage kernels (k_sweep_side takes the model at
+    // run time; the Farneback kernels are built with it for float32 volumes only -- fdn_device.h, fold_warped)
+    if (h->tn.remap_model == 1 && p->warp_mode != FDN_WARP_F32) return 2;
     bool fused = fused_supported(p->winsize, p->iters, H, W) && h->tn.path == 0 && !h->tn.strict_order;
     for (size_t k = 1; k < lv.size(); k++) fused = fused && fused_supported(p->winsize, p->iters, lv[k].h, lv[k].w);
     if (fused) return 0;

@@ -436,13 +436,18 @@ static __device__ __forceinline__ double remap_sample_f64(const double* __restri
 //   1  seq on an integer MRC: the padded volume is float64 (seq:88-89): cv2.remap's CV_64F path (table weights widened,
 //      products and sums in double, no rounding to float); `pad`: the neighbour is a pad slice, the constant float64 mean
 //   2  par on an integer MRC: the neighbour is an integer image: remap rounds half to even and saturates (lo, hi)
-template <int WM>
+//   UNQ (compile time: the "remap_model" option): unquantised float32 bilinear instead of the 1/32-pixel table.  A template
+//   parameter and not a flag in a register: as a wave-uniform runtime branch it cost the 3-iteration kernel 4.8 % (15.31
+//   against 14.61 ms per launch, same box, round 6) -- one VGPR more and a longer final stage.  The Farneback kernels are built
+//   with it for float32 volumes (WM = 4 = 0 + UNQ); the integer semantics under the unquantised model run on the per-stage
+//   path, whose k_sweep_side is memory-bound and takes the flag at run time.
+template <int WM, bool UNQ = false>
 static __device__ __forceinline__ float fold_warped(const float* __restrict__ src, int H, int W, int x, int y, float2 f, float acc_old,
-                                                    double weight, bool pad, double pad64, float lo, float hi, bool fixed8 = false, bool unq = false)
+                                                    double weight, bool pad, double pad64, float lo, float hi, bool fixed8 = false)
 {
     RemapTaps r;
     // (8-bit images keep their fixed-point table in either remap model: the unquantised model is about float maps on float arithmetic)
-    const bool u = unq && !(WM == 2 && fixed8);
+    const bool u = UNQ && !(WM == 2 && fixed8);
     remap_issue<false>(src, H, W, x, y, f, r, u);
     if (WM == 1) return (float)((double)acc_old + remap_finish_f64(r, pad, pad64, u) * weight);
     //   2  ... and a uint8 one (fixed8, wave-uniform): cv2.remap's 8-bit fixed point, an integer already

@@ -420,8 +420,8 @@ __global__ __launch_bounds__(256 * NB, NB == 2 ? 4 : OCC) void k_farneback_fused
                         } else if (ACC) {
                             // (WM: the dtype semantics of an integer volume, fold_warped in fdn_device.h; the neighbour's stack index decides `pad`)
                             const int q = pb.t0 + b + pd;
-                            const bool pad = WM == 1 && (q < wm.pad_lo || q >= wm.pad_hi);
-                            const float acc_new = fold_warped<WM>(img1, H, W, xc, y, f, acc_old, weight, pad, wm.pad64, wm.lo, wm.hi, wm.fixed8 != 0, wm.model == 1);
+                            const bool pad = (WM & 3) == 1 && (q < wm.pad_lo || q >= wm.pad_hi);
+                            const float acc_new = fold_warped<(WM & 3), (WM & 4) != 0>(img1, H, W, xc, y, f, acc_old, weight, pad, wm.pad64, wm.lo, wm.hi, wm.fixed8 != 0);
                             if (owner) {
                                 if (flow_out) st_off(flow_out, o * 8u, f);
                                 st_off(acc, o * 4u, acc_new);
@@ -523,6 +523,10 @@ static void launch_variant(const float* Rstack, const float* stack, const float*
         if (fin == 2) launch(k_farneback_fused<MH, D, DX, U, OCC, 2, true, NB, 2>);
         else if (fin == 1) launch(k_farneback_fused<MH, D, DX, U, OCC, 1, true, NB, 2>);
         else launch(k_farneback_fused<MH, D, DX, U, OCC, 0, true, NB, 2>);
+    } else if (acc && wm.model == 1) {  // float32 volume, unquantised remap (the "remap_model" option): WM = 4
+        if (fin == 2) launch(k_farneback_fused<MH, D, DX, U, OCC, 2, true, NB, 4>);
+        else if (fin == 1) launch(k_farneback_fused<MH, D, DX, U, OCC, 1, true, NB, 4>);
+        else launch(k_farneback_fused<MH, D, DX, U, OCC, 0, true, NB, 4>);
     } else if (acc) {
         if (fin == 2) launch(k_farneback_fused<MH, D, DX, U, OCC, 2, true, NB, 0>);
         else if (fin == 1) launch(k_farneback_fused<MH, D, DX, U, OCC, 1, true, NB, 0>);

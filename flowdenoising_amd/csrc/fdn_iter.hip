@@ -196,9 +196,9 @@ __global__ __launch_bounds__(ACC ? 192 : 128) void k_farneback_iter(const float*
                 const float2 f = fho[(y & 1) * 64 + lane];
                 const unsigned o = (unsigned)y * (unsigned)W + (unsigned)xc;
                 const int q = pb.t0 + b + d;           // (WM: integer-volume semantics, warped_value in fdn_device.h)
-                const bool pad = WM == 1 && (q < wm.pad_lo || q >= wm.pad_hi);
+                const bool pad = (WM & 3) == 1 && (q < wm.pad_lo || q >= wm.pad_hi);
                 const float acc_old = ld_off<float>(acc, o * 4u);
-                const float acc_new = fold_warped<WM>(img1, H, W, xc, y, f, acc_old, weight, pad, wm.pad64, wm.lo, wm.hi, wm.fixed8 != 0, wm.model == 1);
+                const float acc_new = fold_warped<(WM & 3), (WM & 4) != 0>(img1, H, W, xc, y, f, acc_old, weight, pad, wm.pad64, wm.lo, wm.hi, wm.fixed8 != 0);
                 if (owner) st_off(acc, o * 4u, acc_new);
             }
             lds_barrier_iter();
@@ -361,6 +361,11 @@ static int launch_iter_t(const float* Rstack, const float* stack, const float* f
         if (fin == 2) return launch(k_farneback_iter<MHT, 2, true, 2>);
         if (fin == 1) return launch(k_farneback_iter<MHT, 1, true, 2>);
         return launch(k_farneback_iter<MHT, 0, true, 2>);
+    }
+    if (acc && wm.model == 1) {         // float32 volume, unquantised remap (the "remap_model" option): WM = 4
+        if (fin == 2) return launch(k_farneback_iter<MHT, 2, true, 4>);
+        if (fin == 1) return launch(k_farneback_iter<MHT, 1, true, 4>);
+        return launch(k_farneback_iter<MHT, 0, true, 4>);
     }
     if (acc) {
         if (fin == 2) return launch(k_farneback_iter<MHT, 2, true, 0>);

@@ -1033,7 +1033,7 @@ def test_sub_batches_on_two_streams_give_the_same_bits(fdn, case):
 
 def test_handles_used_from_threads_in_this_process(fdn, oracle):
     """Multi-threaded use of the library INSIDE the long-lived test process (most multi-threaded GPU tests run in processes
-    of their own, conftest.run_in_fresh_process): four threads share the process-wide handle through the pair operators (the
+    of their own, see conftest): four threads share the process-wide handle through the pair operators (the
     C ABI takes the handle's lock), three more own a handle each -- created in the thread, closed by the main thread, the
     out-of-core mode's pattern -- and run sweeps at the same time; then the out-of-core mode itself; then an ordinary
     single-threaded filter of a fresh 1.1 MB volume, the kind of call round 5's sessions aborted in (NOTES_r06.md section 2).
