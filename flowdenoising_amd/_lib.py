@@ -49,7 +49,7 @@ EXPORTS = [
     "fdn_memset_f32", "fdn_gaussian_kernel", "fdn_farneback", "fdn_farneback_strided", "fdn_farneback_dev",
     "fdn_warp", "fdn_warp_strided", "fdn_warp_dev", "fdn_farneback_typed", "fdn_warp_typed",
     "fdn_filter_axis_dev", "fdn_filter_axis", "fdn_filter_3d_dev", "fdn_filter_3d",
-    "fdn_mean_host", "fdn_mean_dev", "fdn_np_chunk_sums_dev", "fdn_sum_dev", "fdn_stats_dev", "fdn_stats_slices_dev", "fdn_convert_dev", "fdn_truncate_dev", "fdn_reserve_3d", "fdn_filter_3d_sharded", "fdn_sweep_stack_dev", "fdn_permute_dev",
+    "fdn_mean_host", "fdn_mean_dev", "fdn_np_chunk_sums_dev", "fdn_sum_dev", "fdn_stats_dev", "fdn_stats_slices_dev", "fdn_convert_dev", "fdn_truncate_dev", "fdn_reserve_3d", "fdn_reserve_stack", "fdn_filter_3d_sharded", "fdn_sweep_stack_dev", "fdn_permute_dev",
     "fdn_enable_timers", "fdn_get_timers", "fdn_add_timer", "fdn_version",
 ]
 
@@ -607,6 +607,10 @@ class Handle:
         check(self._lib.fdn_sweep_stack_dev(self._h, ctypes.c_void_p(d_stack), ctypes.c_void_p(d_out), ctypes.c_int(S),
                                             ctypes.c_int(H), ctypes.c_int(W), _ptr(kernel), ctypes.c_int(kernel.size),
                                             ctypes.byref(params)))
+
+    def reserve_stack(self, S, H, W, K, params):
+        """Allocate what sweep_stack_dev(S, H, W, K taps, params) will use; launches nothing (fdn_reserve_stack)."""
+        check(self._lib.fdn_reserve_stack(self._h, ctypes.c_int(S), ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(K), ctypes.byref(params)))
 
     def permute_dev(self, d_in, d_out, dims, strides):
         A, B, C = dims

@@ -2108,6 +2108,18 @@ FDN_API int fdn_reserve_3d(fdn_handle h, int Z, int Y, int X, const int K[3], co
     return rc;
 }
 
+FDN_API int fdn_reserve_stack(fdn_handle h, int S, int H, int W, int K, const fdn_sweep_params* p)
+{
+    FDN_ENTER(h);
+    if (S <= 0 || H <= 0 || W <= 0 || K <= 0) return fail("bad stack dims S=%d H=%d W=%d K=%d", S, H, W, K);
+    std::vector<double> taps((size_t)K, 1.0);          // never read: nothing is launched
+    float* const fake = (float*)(uintptr_t)16;
+    h->reserve_only = true;
+    const int rc = sweep_stack(h, fake, fake, S, H, W, taps.data(), K, p);
+    h->reserve_only = false;
+    return rc;
+}
+
 FDN_API int fdn_stats_dev(fdn_handle h, const float* d_in, size_t count, double* out4)
 {
     FDN_ENTER(h);

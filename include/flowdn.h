@@ -337,6 +337,10 @@ int fdn_filter_3d_sharded(fdn_handle h, const float* d_slab_in, float* d_slab_ou
  * has filled (neighbour data, pad value, or wrapped copies).  Writes S images to d_out. */
 int fdn_sweep_stack_dev(fdn_handle h, const float* d_stack, float* d_out, int S, int H, int W,
                         const double* kernel, int K, const fdn_sweep_params* p);
+/* Allocate what fdn_sweep_stack_dev will use for a stack of this shape, tap count and parameters, and launch nothing (the
+ * fdn_reserve_3d of the slab primitive): the out-of-core mode sizes every worker's buffers before its first chunk, so that
+ * no chunk waits for gigabytes of hipMalloc. */
+int fdn_reserve_stack(fdn_handle h, int S, int H, int W, int K, const fdn_sweep_params* p);
 /* out[a][b][c] = in[a*sa + b*sb + c*sc]; out is contiguous with dims (A,B,C); strides in
  * elements.  Used for the Z->Y->X slab re-orientation between passes. */
 int fdn_permute_dev(fdn_handle h, const float* d_in, float* d_out, int A, int B, int C,

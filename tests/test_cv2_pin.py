@@ -313,6 +313,42 @@ def test_remap_model_diagnostic_tells_the_two_models_apart(oracle):
 
 
 
+@pytest.mark.parametrize("fma,lanes,model", [(0, 8, 0), (1, 8, 1), (2, 8, 1), (2, 4, 0)])
+def test_option_matcher_finds_the_settings_of_a_stand_in(oracle, fma, lanes, model):
+    """tools/make_cv2_golden.py records, next to a real cv2's version and build lines, which values of the product's switches
+    for the two cv2 unknowns reproduce it bit for bit (`opencv_fma` / `opencv_fma_lanes`, `remap_model`).  Here a stand-in cv2
+    that IS the oracle in one of those settings must be identified as exactly that setting."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools"))
+    import make_cv2_golden as M
+
+    class StandIn:
+        __version__ = f"stand-in fma {fma}/{lanes} remap {model}"
+        OPTFLOW_USE_INITIAL_FLOW, INTER_LINEAR, BORDER_REPLICATE = 4, 1, 1
+
+        @staticmethod
+        def calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags):
+            oracle.set_fma(fma, lanes)
+            try:
+                return oracle.calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags)
+            finally:
+                oracle.set_fma(0)
+
+        @staticmethod
+        def remap(src, m, _, interpolation, borderMode):
+            oracle.set_remap_model(model)
+            try:
+                return oracle.remap_any(src, m)
+            finally:
+                oracle.set_remap_model(0)
+
+    import types
+    T = types.SimpleNamespace(make_pair=make_pair, cv2_warp=cv2_warp, cv2_flow=cv2_flow)
+    res = M.which_options_match(StandIn, T, oracle)
+    assert res["remap_model"] == model
+    assert res["opencv_fma"] == {"mode": fma, "lanes": 8 if fma < 2 else lanes}, res
+
+
 def test_harness_sweep_is_seq_shaped(oracle):
     """cv2_of_filter / cv2_flow / cv2_warp above are this file's own code; so that they are known to be right on
     the day cv2 appears, they are run here with a stand-in object whose two functions forward to the oracle:

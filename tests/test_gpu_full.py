@@ -1088,7 +1088,9 @@ def test_handles_used_from_threads_in_this_process(fdn, oracle):
     for i in range(3):
         assert np.array_equal(got[("sweep", i)], want_sweep[r:r + S])
     streamed = streaming.filter_streamed(vol, [k, k, None], 0, 5, chunk_slices=3)
-    assert np.array_equal(streamed, fdn.OF_filter(vol, [k, k, None], 0, 5))
+    again = streaming.filter_streamed(vol, [k, k, None], 0, 5, chunk_slices=5, workers=2)      # the kept workers, another chunking
+    streaming.release_workers()
+    assert np.array_equal(streamed, fdn.OF_filter(vol, [k, k, None], 0, 5)) and np.array_equal(again, streamed)
     fresh = _vol((7, 130, 300), seed=33)
     out = fdn.OF_filter(fresh, [k, None, k], 0, 5)
     assert np.array_equal(out, oracle.OF_filter(fresh, [k, None, k], 0, 5, nthreads=8))

@@ -18,6 +18,36 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def which_options_match(cv2, T, O):
+    """Which of the product's / the oracle's switches for the two cv2 unknowns reproduce THIS cv2 bit for bit: `remap_model`
+    (0 = the 1/32-pixel table, 1 = unquantised float32 bilinear) on a warp, `opencv_fma` x `opencv_fma_lanes` on pyramid flows
+    (levels 3, window 5 and 15, images whose rows are not multiples of 16).  The answer goes into cv2_identity.json next to the
+    version and build lines: on that box `flowdenoising.py --opencv_fma M --opencv_fma_lanes L --remap_model R`, or
+    fdn_set_option / fdo_set_fma / fdo_set_remap_model, select the matching arithmetic -- no kernel has to be written."""
+    res = {"remap_model": None, "opencv_fma": None, "tried": []}
+    a, b, f0 = T.make_pair((70, 150), 171)
+    flow = (f0 * 3).astype(np.float32)
+    want = T.cv2_warp(cv2, b, flow)
+    for model in (0, 1):
+        O.set_remap_model(model)
+        try:
+            if np.array_equal(O.warp_slice(b, flow), want):
+                res["remap_model"] = model
+        finally:
+            O.set_remap_model(0)
+    wants = {(l, w): T.cv2_flow(cv2, a, b, l, w, f0) for (l, w) in ((3, 5), (3, 15))}
+    for mode, lanes in ((0, 8), (1, 8), (2, 4), (2, 8), (2, 16)):
+        O.set_fma(mode, lanes)
+        try:
+            errs = {f"l{l}w{w}": float(np.abs(O.get_flow(b, a, l, w, f0.copy()) - wants[(l, w)]).max()) for (l, w) in wants}
+        finally:
+            O.set_fma(0)
+        res["tried"].append({"opencv_fma": mode, "lanes": lanes, "max_abs_flow_diff": errs})
+        if all(v == 0.0 for v in errs.values()) and res["opencv_fma"] is None:
+            res["opencv_fma"] = {"mode": mode, "lanes": lanes}
+    return res
+
+
 def main():
     import cv2
     import test_cv2_pin as T
@@ -32,6 +62,10 @@ def main():
     a0, b0, f00 = T.make_pair((64, 64), 164)
     fl = (f00 * 3).astype(np.float32)
     print("remap model:", T.classify_remap(b0, fl, T.cv2_warp(cv2, b0, fl), O0.warp_slice(b0, fl).astype(np.float64)))
+    ident["matched"] = which_options_match(cv2, T, O0)
+    print("options that reproduce this cv2 bit for bit:", ident["matched"])
+    with open(os.path.join(T.GOLD, "cv2_identity.json"), "w") as f:      # ... now with the matching option values
+        json.dump(ident, f, indent=1)
     for shape in T.PAIR_SHAPES[:2]:
         for l, w in T.PAIR_PARAMS:
             a, b, f0 = T.make_pair(shape, 100 + shape[0])
