@@ -217,6 +217,18 @@ def sweep_line(h, vol, shape, kernel, params, mean):
                     "SURVEY 8(d)'s sweep model, which is also what the kernel moves; per-stage path (fdn_set_option path = 1)"}
 
 
+def to_host(h, t):
+    """A device tensor's values as a numpy array, copied by the library (fdn_memcpy_d2h: page-locked for the call or bounced,
+    DESIGN.md 2) and not by `tensor.cpu()`: a pageable copy of this size is page-locked by the HIP runtime on the fly, the
+    path the GPU memory fault of profiles/history/NOTES_r06.md section 2 was caught in."""
+    import torch
+    t = t.contiguous()
+    torch.cuda.synchronize()
+    arr = np.empty(tuple(t.shape), dtype=np.float32)
+    h.d2h(arr, t.data_ptr())
+    return arr
+
+
 def check_output(h, vol, out, shape, kernels, params, mean):
     """After the timed region: redo the step pass by pass (so that each pass's input exists), require the same bits
     as the timed output, and recompute one target slice of every pass with the oracle from that pass's own input."""
@@ -240,9 +252,9 @@ def check_output(h, vol, out, shape, kernels, params, mean):
         lo, hi = max(0, t - r), min(n, t + r + 1)
         idx = [slice(None)] * 3
         idx[axis] = slice(lo, hi)
-        sub = cur[tuple(idx)].contiguous().cpu().numpy()
+        sub = to_host(h, cur[tuple(idx)])
         idx[axis] = t
-        got = nxt[tuple(idx)].contiguous().cpu().numpy()
+        got = to_host(h, nxt[tuple(idx)])
         nthr = min(16, len(os.sched_getaffinity(0)))      # the oracle spreads the slice's Farneback pairs over threads
         want = np.take(O.filter_axis_range(sub, axis, k, params.levels, params.winsize, mean, t - lo, t - lo + 1, nthreads=nthr),
                        t - lo, axis=axis)
@@ -266,7 +278,7 @@ def check_output(h, vol, out, shape, kernels, params, mean):
             "how": "one target slice per pass recomputed by the CPU oracle from the GPU's input of that pass"}
 
 
-def cpu_baseline(vol_t, shape, kernel, mean, n_targets, levels, winsize):
+def cpu_baseline(h, vol_t, shape, kernel, mean, n_targets, levels, winsize):
     """Time the oracle's Z pass on `n_targets` target slices taken from the middle of the same
     volume, one chunk of slices per core (par:181-206), and scale to the full three-pass job."""
     from oracle import oracle as O
@@ -281,7 +293,7 @@ def cpu_baseline(vol_t, shape, kernel, mean, n_targets, levels, winsize):
     n_targets = min(n_targets, Z)
     z0 = max(0, Z // 2 - n_targets // 2 - r)
     z1 = min(Z, z0 + n_targets + 2 * r)
-    slab = vol_t[z0:z1].cpu().numpy()
+    slab = to_host(h, vol_t[z0:z1])
     s0 = min(r, slab.shape[0] - n_targets)
     t0 = time.perf_counter()
     O.filter_axis_range(slab, 0, kernel, levels, winsize, mean, s0, s0 + n_targets, nthreads=cores)
@@ -788,7 +800,7 @@ def run(a, job, fallback):
     h.enable_timers(False)
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(vol, shape, kernel, mean, a.cpu_targets, a.levels, a.winsize)
+            res["cpu_baseline"] = cpu_baseline(h, vol, shape, kernel, mean, a.cpu_targets, a.levels, a.winsize)
         elif world > 1:
             res["cpu_baseline"] = None
             res["cpu_baseline_see"] = "the N = 1 line: the CPU sample is timed on rank 0 at N = 1 only"

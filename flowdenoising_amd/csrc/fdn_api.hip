@@ -239,6 +239,69 @@ static void resolve_stamps(fdn_ctx* h)
     h->stamps.clear();
 }
 
+// ---- FDN_GUARD_ALLOC=1: a debugging allocator (never the default) ---------------------------------------------------------
+// Every device buffer the library allocates -- its own workspaces and what fdn_malloc hands out -- is placed through HIP's
+// virtual-memory API so that the bytes right after its end (and the pages before its mapping) are NOT mapped: a kernel that
+// reads or writes past the end of a buffer then faults at once and reproducibly, instead of silently touching a neighbour
+// (there is no GPU AddressSanitizer on this pool).  A clean run of the parity tests under it is evidence that no kernel
+// addresses beyond its operands (profiles/history/NOTES_r06.md, section 8).  Buffers end 16-byte aligned at the mapping's end.
+struct GuardBlock { void* va; size_t va_bytes; size_t map_bytes; hipMemGenericAllocationHandle_t handle; };
+static std::mutex g_guard_mu;
+static std::map<void*, GuardBlock> g_guard;
+static bool guard_mode()
+{
+    static const bool on = [] { const char* e = getenv("FDN_GUARD_ALLOC"); return e && atoi(e) != 0; }();
+    return on;
+}
+static hipError_t guard_malloc(void** out, size_t bytes, int device)
+{
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess) return e;
+    if (!gran) gran = 4096;
+    const size_t need = (std::max<size_t>(bytes, 1) + 15) & ~(size_t)15;
+    GuardBlock g;
+    g.map_bytes = (need + gran - 1) / gran * gran;
+    g.va_bytes = g.map_bytes + 2 * gran;
+    if ((e = hipMemAddressReserve(&g.va, g.va_bytes, gran, nullptr, 0)) != hipSuccess) return e;
+    if ((e = hipMemCreate(&g.handle, g.map_bytes, &prop, 0)) != hipSuccess) { (void)hipMemAddressFree(g.va, g.va_bytes); return e; }
+    char* base = (char*)g.va + gran;                       // one unmapped granule before, one after
+    if ((e = hipMemMap(base, g.map_bytes, 0, g.handle, 0)) != hipSuccess) { (void)hipMemRelease(g.handle); (void)hipMemAddressFree(g.va, g.va_bytes); return e; }
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if ((e = hipMemSetAccess(base, g.map_bytes, &acc, 1)) != hipSuccess) { (void)hipMemUnmap(base, g.map_bytes); (void)hipMemRelease(g.handle); (void)hipMemAddressFree(g.va, g.va_bytes); return e; }
+    *out = base + (g.map_bytes - need);                    // the buffer ENDS where the mapping ends
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guard[*out] = g;
+    return hipSuccess;
+}
+static hipError_t dev_malloc(void** out, size_t bytes, int device)
+{
+    return guard_mode() ? guard_malloc(out, bytes, device) : hipMalloc(out, bytes);
+}
+static hipError_t dev_free(void* p)
+{
+    if (!guard_mode() || !p) return hipFree(p);
+    GuardBlock g;
+    {
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        auto it = g_guard.find(p);
+        if (it == g_guard.end()) return hipFree(p);
+        g = it->second;
+        g_guard.erase(it);
+    }
+    (void)hipDeviceSynchronize();
+    size_t gran = (g.va_bytes - g.map_bytes) / 2;
+    (void)hipMemUnmap((char*)g.va + gran, g.map_bytes);
+    (void)hipMemRelease(g.handle);
+    return hipMemAddressFree(g.va, g.va_bytes);
+}
+
 static int ensure(fdn_ctx* h, DevBuf& b, size_t bytes)
 {
     // under a workspace limit a buffer is also given back when it is more than a quarter (and more than 16 MB, or
@@ -254,10 +317,10 @@ static int ensure(fdn_ctx* h, DevBuf& b, size_t bytes)
     if (b.p) FDN_HIP(hipStreamSynchronize(h->stream));
     FDN_DEVICE_WIDE;
     if (b.p) {
-        FDN_HIP(hipFree(b.p));
+        FDN_HIP(dev_free(b.p));
         b.p = nullptr; b.cap = 0;
     }
-    hipError_t e = hipMalloc(&b.p, bytes);
+    hipError_t e = dev_malloc(&b.p, bytes, h->device);
     if (e != hipSuccess) { b.p = nullptr; return fail("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
     b.cap = bytes;
     return 0;
@@ -266,7 +329,7 @@ static int ensure(fdn_ctx* h, DevBuf& b, size_t bytes)
 static void release(DevBuf& b)
 {
     FDN_DEVICE_WIDE;
-    if (b.p) (void)hipFree(b.p);
+    if (b.p) (void)dev_free(b.p);
     b.p = nullptr; b.cap = 0;
 }
 
@@ -445,7 +508,7 @@ static void free_all(fdn_ctx* h)
                       &h->vol_in, &h->vol_out, &h->Rpyr, &h->flow_pyr, &h->pyr_tmp, &h->area_tab,
                       &h->sh_send, &h->sh_recv, &h->sh_stack, &h->sh_out[0], &h->sh_out[1], &h->sh_tmp};
     FDN_DEVICE_WIDE;
-    for (DevBuf* b : bufs) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    for (DevBuf* b : bufs) { if (b->p) (void)dev_free(b->p); b->p = nullptr; b->cap = 0; }
     h->area_key = {0, 0, 0, 0};
 }
 
@@ -1643,7 +1706,7 @@ FDN_API int fdn_malloc(fdn_handle h, size_t bytes, void** dptr)
     FDN_ENTER(h);
     if (!dptr) return fail("dptr is NULL");
     FDN_DEVICE_WIDE;
-    FDN_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    FDN_HIP(dev_malloc(dptr, bytes ? bytes : 1, h->device));
     return 0;
 }
 FDN_API int fdn_free(fdn_handle h, void* dptr)
@@ -1651,7 +1714,7 @@ FDN_API int fdn_free(fdn_handle h, void* dptr)
     FDN_ENTER(h);
     FDN_HIP(hipStreamSynchronize(h->stream));
     FDN_DEVICE_WIDE;
-    if (dptr) FDN_HIP(hipFree(dptr));
+    if (dptr) FDN_HIP(dev_free(dptr));
     return 0;
 }
 FDN_API int fdn_memcpy_h2d(fdn_handle h, void* dst, const void* src, size_t bytes)

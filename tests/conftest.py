@@ -94,6 +94,20 @@ def run_in_fresh_process(code, arrays, tmp_path, timeout=600, env=None):
     return {k: got[k] for k in got.files}, r.stdout
 
 
+def to_host(t):
+    """A torch device tensor's values as a numpy array, copied by the library (fdn_memcpy_d2h: page-locked for the call or
+    bounced) instead of `tensor.cpu()`: large pageable copies are page-locked by the HIP runtime on the fly -- the path the GPU
+    memory fault of profiles/history/NOTES_r06.md section 2 was caught in; the long-lived test process stays off it."""
+    import numpy as np
+    import torch
+    from flowdenoising_amd.operators import handle
+    t = t.contiguous()
+    torch.cuda.synchronize()
+    arr = np.empty(tuple(t.shape), dtype=np.float32)
+    handle().d2h(arr, t.data_ptr())
+    return arr
+
+
 def rel_err(a, b):
     """max |a-b| / max |b|: the volume-range-relative error the 1e-4 bar is stated in."""
     import numpy as np

@@ -416,3 +416,42 @@ def test_gpu_tests_that_start_processes_are_marked():
             if starts and "mark.gpu_subprocess" not in decorators:
                 missing.append(f"{os.path.basename(path)}::{node.name}")
     assert not missing, f"GPU tests that start processes without @pytest.mark.gpu_subprocess: {missing}"
+
+
+def test_the_command_line_script_keeps_the_parent_of_a_multi_gpu_run_off_the_gpu():
+    """flowdenoising.py opens the GPU context in a thread while numpy is imported -- except in the parent of `--gpus N`, which
+    must never touch a GPU (its rank processes do), whatever spelling of the option argparse accepts (it takes unambiguous
+    prefixes), and never under a launcher's rank variables.  The thread is named, so that the first real handle can wait for it."""
+    src = open(os.path.join(ROOT, "flowdenoising.py")).read().split('if __name__ == "__main__":')[0]
+    ns = {"__file__": os.path.join(ROOT, "flowdenoising.py"), "__name__": "flowdenoising_under_test"}
+    exec(compile(src, "flowdenoising.py", "exec"), ns)
+    started = []
+
+    class FakeThread:
+        def __init__(self, target=None, args=(), daemon=None, name=None):
+            self.args, self.name = args, name
+
+        def start(self):
+            started.append((self.name, self.args))
+
+        def join(self, timeout=None):
+            pass
+
+    ns["threading"].Thread, real = FakeThread, ns["threading"].Thread
+    saved = {k: os.environ.pop(k) for k in ("FDN_RANK", "RANK", "FDN_SYSTEM_ROCM") if k in os.environ}
+    try:
+        for argv, device in ((["-i", "a.mrc"], 0), (["--device", "3"], 3), (["--dev=2", "-n"], 2),
+                             (["--gpus", "2"], None), (["--gpus=4"], None), (["--gpu", "2"], None), (["--gp", "2"], None), (["-h"], None)):
+            started.clear()
+            ns["_early_start"](argv)
+            assert started == ([] if device is None else [(ns["WARM_THREAD_NAME"], (device,))]), (argv, started)
+        os.environ["RANK"] = "0"
+        started.clear()
+        ns["_early_start"](["-i", "a.mrc"])
+        assert started == []
+    finally:
+        ns["threading"].Thread = real
+        os.environ.pop("RANK", None)
+        os.environ.pop("FDN_SYSTEM_ROCM", None)
+        os.environ.update(saved)
+    assert ns["WARM_THREAD_NAME"] in open(os.path.join(ROOT, "flowdenoising_amd", "operators.py")).read()

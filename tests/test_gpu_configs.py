@@ -14,7 +14,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import rel_err, to_host
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -91,9 +91,9 @@ def test_config2_each_pass_of_the_full_volume(fdn, oracle):
                 lo, hi = max(0, t - 8), min(n, t + 9)
                 idx = [slice(None)] * 3
                 idx[axis] = slice(lo, hi)
-                sub = cur[tuple(idx)].contiguous().cpu().numpy()
+                sub = to_host(cur[tuple(idx)])
                 idx[axis] = t
-                checks.append((axis, t, lo, sub, out[tuple(idx)].contiguous().cpu().numpy()))
+                checks.append((axis, t, lo, sub, to_host(out[tuple(idx)])))
             vols[axis] = out
             cur = out
         whole = torch.empty_like(vol)

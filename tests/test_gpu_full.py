@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import rel_err, to_host
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -536,8 +536,8 @@ def test_wide_kernel_on_a_gib_volume_spot_parity(fdn, oracle):
         h.filter_3d_dev(vol.data_ptr(), out.data_ptr(), shape, [k, None, None], mean, params)
         torch.cuda.synchronize()
         t = 500
-        sub = vol[t - 16:t + 17].cpu().numpy()
-        got = out[t].cpu().numpy()
+        sub = to_host(vol[t - 16:t + 17])
+        got = to_host(out[t])
     finally:
         h.close()
         del vol, out
