@@ -245,6 +245,8 @@ static void resolve_stamps(fdn_ctx* h)
 // reads or writes past the end of a buffer then faults at once and reproducibly, instead of silently touching a neighbour
 // (there is no GPU AddressSanitizer on this pool).  A clean run of the parity tests under it is evidence that no kernel
 // addresses beyond its operands (profiles/history/NOTES_r06.md, section 8).  Buffers end 16-byte aligned at the mapping's end.
+// FDN_GUARD_ALLOC=2 / 3 additionally fill a fresh block with 0xFF bytes (NaNs) / zeros: a result that depends on the fill is a
+// read of memory nobody wrote.  FDN_GUARD_ONLY=<names> guards only the named buffers.
 struct GuardBlock { void* va; size_t va_bytes; size_t map_bytes; hipMemGenericAllocationHandle_t handle; };
 static std::mutex g_guard_mu;
 static std::map<void*, GuardBlock> g_guard;
@@ -275,14 +277,32 @@ static hipError_t guard_malloc(void** out, size_t bytes, int device)
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
     if ((e = hipMemSetAccess(base, g.map_bytes, &acc, 1)) != hipSuccess) { (void)hipMemUnmap(base, g.map_bytes); (void)hipMemRelease(g.handle); (void)hipMemAddressFree(g.va, g.va_bytes); return e; }
+    // FDN_GUARD_ALLOC=2: the fresh mapping filled with 0xFF bytes (float NaNs), 3: with zeros -- a result that depends on the
+    // fill is a read of memory nobody wrote
+    {
+        const char* ev = getenv("FDN_GUARD_ALLOC");
+        const int mode = ev ? atoi(ev) : 0;
+        if (mode == 2 || mode == 3) { (void)hipMemset(base, mode == 2 ? 0xFF : 0, g.map_bytes); (void)hipDeviceSynchronize(); }
+    }
     *out = base + (g.map_bytes - need);                    // the buffer ENDS where the mapping ends
     std::lock_guard<std::mutex> lk(g_guard_mu);
     g_guard[*out] = g;
     return hipSuccess;
 }
-static hipError_t dev_malloc(void** out, size_t bytes, int device)
+// FDN_GUARD_ONLY=<name>[,<name>...]: guard only these buffers (R, flow, stack, sweep_out, vol_a, vol_b, partials, pair, vol_in,
+// vol_out, Rpyr, flow_pyr, pyr_tmp, area_tab, M0, M1, sh, user = fdn_malloc): to find which placement a failure depends on
+static bool guard_wanted(const char* name)
 {
-    return guard_mode() ? guard_malloc(out, bytes, device) : hipMalloc(out, bytes);
+    const char* only = getenv("FDN_GUARD_ONLY");
+    if (!only || !*only) return true;
+    const size_t n = strlen(name);
+    for (const char* p = only; (p = strstr(p, name)) != nullptr; p += n)
+        if ((p == only || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return true;
+    return false;
+}
+static hipError_t dev_malloc(void** out, size_t bytes, int device, const char* name = "user")
+{
+    return guard_mode() && guard_wanted(name) ? guard_malloc(out, bytes, device) : hipMalloc(out, bytes);
 }
 static hipError_t dev_free(void* p)
 {
@@ -296,6 +316,11 @@ static hipError_t dev_free(void* p)
         g_guard.erase(it);
     }
     (void)hipDeviceSynchronize();
+    // A guarded block is never unmapped (its memory is leaked; guard mode is for small test volumes): on this stack, unmapping and
+    // releasing a mapping and then mapping new memory at the address range the runtime hands out next leaves the GPU with the OLD
+    // translation -- every result after the first re-allocation of a workspace was garbage, and none with this early return
+    // (round 6, tools/scratch/guard_case.py; FDN_GUARD_FREE=1 restores the unmapping to show it).
+    { const char* e = getenv("FDN_GUARD_FREE"); if (!e || !atoi(e)) return hipSuccess; }
     size_t gran = (g.va_bytes - g.map_bytes) / 2;
     (void)hipMemUnmap((char*)g.va + gran, g.map_bytes);
     (void)hipMemRelease(g.handle);
@@ -320,7 +345,11 @@ static int ensure(fdn_ctx* h, DevBuf& b, size_t bytes)
         FDN_HIP(dev_free(b.p));
         b.p = nullptr; b.cap = 0;
     }
-    hipError_t e = dev_malloc(&b.p, bytes, h->device);
+    const char* name = &b == &h->R ? "R" : &b == &h->flow ? "flow" : &b == &h->stack ? "stack" : &b == &h->sweep_out ? "sweep_out" : &b == &h->vol_a ? "vol_a"
+                     : &b == &h->vol_b ? "vol_b" : &b == &h->partials ? "partials" : &b == &h->pair ? "pair" : &b == &h->vol_in ? "vol_in" : &b == &h->vol_out ? "vol_out"
+                     : &b == &h->Rpyr ? "Rpyr" : &b == &h->flow_pyr ? "flow_pyr" : &b == &h->pyr_tmp ? "pyr_tmp" : &b == &h->area_tab ? "area_tab" : &b == &h->M0 ? "M0"
+                     : &b == &h->M1 ? "M1" : "sh";
+    hipError_t e = dev_malloc(&b.p, bytes, h->device, name);
     if (e != hipSuccess) { b.p = nullptr; return fail("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
     b.cap = bytes;
     return 0;

@@ -372,3 +372,29 @@ def test_flower_protocol(fdn, oracle):
     assert np.array_equal(cold.get_flow(vol[1]), oracle.calcOpticalFlowFarneback(vol[0], vol[1], None, 0.5, 0, 7, 3, 5, 1.2, 0))
     with pytest.raises(RuntimeError):
         fdn.CPU_flower().get_flow(vol[0], flow)
+
+
+@pytest.mark.parametrize("shape,l,w", [((14, 131, 97), 2, 5), ((14, 131, 97), 0, 5), ((14, 70, 150), 3, 15), ((12, 33, 61), 0, 7)])
+def test_results_do_not_depend_on_the_alignment_of_device_pointers(fdn, shape, l, w):
+    """fdn_sweep_stack_dev on a caller's device pointers that are only 4-byte aligned -- a slab view `volume[z0:z1]` of a volume
+    with odd-sized images is -- gives the bits of the 256-byte aligned call: no kernel assumes more than the element's alignment
+    (the polynomial expansion's 8- and 16-byte loads address library-owned buffers)."""
+    from flowdenoising_amd.operators import _params, handle
+    vol = _vol(shape, seed=21)
+    k = fdn.get_gaussian_kernel(1.0)
+    r = k.size // 2
+    S, H, W = shape[0] - 2 * r, shape[1], shape[2]
+    h = handle()
+    outs = []
+    for off_in, off_out in ((0, 0), (4, 0), (8, 4), (36, 20)):
+        d_in, d_out = h.malloc(vol.nbytes + 256), h.malloc(S * H * W * 4 + 256)
+        try:
+            h.h2d(d_in + off_in, vol)
+            h.sweep_stack_dev(d_in + off_in, d_out + off_out, S, H, W, k, _params(l, w))
+            out = np.empty((S, H, W), np.float32)
+            h.d2h(out, d_out + off_out)
+        finally:
+            h.free(d_in)
+            h.free(d_out)
+        outs.append(out)
+    assert all(np.array_equal(o, outs[0]) for o in outs[1:])
