@@ -201,6 +201,8 @@ def filter_3d_own_mean(vol, kernel, params, device=0, stats=None, float32_semant
             # page-locked where the runtime allows it: the upload then reads the page cache directly -- no host copy at all
             try:
                 pin_in = big and hu.host_register(src)
+                if timing is not None:
+                    timing["in_pinned"] = bool(pin_in)
                 try:
                     hu.h2d(d_out if raw_int else d_in, src)      # raw integers into the (larger) output buffer first
                 finally:
