@@ -231,3 +231,42 @@ def test_a_user_supplied_rendezvous_directory_gets_a_subdirectory_per_job(fdn, t
     assert "child: rank 0 ok" in res[0][1]
     assert (tmp_path / "rdv" / "error.1").exists()                 # the user's directory itself is left alone ...
     assert [n for n in os.listdir(tmp_path / "rdv") if n.startswith("fdn_rdv_")] == []   # ... and the job's own part is gone
+
+
+def test_spawn_ends_a_job_that_is_overdue_or_whose_failed_rank_cannot_leave(fdn):
+    """launch.spawn has a deadline of its own (FDN_NATIVE_DEADLINE / `deadline`), and a rank that has REPORTED a failure but is
+    stuck on its way out (a helper thread still inside RCCL after an initialisation that ran into its own deadline) does not keep
+    the parent waiting: the report in the rendezvous directory ends the job."""
+    import time
+    from flowdenoising_amd import launch
+    forever = "import time; time.sleep(300)"
+    t0 = time.perf_counter()
+    errors = []
+    assert launch.spawn([sys.executable, "-c", forever], 2, deadline=2.0, errors=errors) != 0
+    assert time.perf_counter() - t0 < 40 and any("did not finish within" in e for e in errors), errors
+    stuck = ("import os, sys, time; sys.path.insert(0, %r)\n"
+             "from flowdenoising_amd import launch\n"
+             "r, w, l, rdv = launch.job()\n"
+             "if r == 1:\n"
+             "    launch.report_failure(rdv, r, 'RuntimeError: the links are down')\n"
+             "time.sleep(300)\n") % ROOT
+    t0 = time.perf_counter()
+    errors = []
+    assert launch.spawn([sys.executable, "-c", stuck], 2, errors=errors) != 0
+    assert time.perf_counter() - t0 < 40 and any("the links are down" in e for e in errors), errors
+
+
+def test_make_transport_failure_reports_and_ends_the_rank_at_once(fdn, tmp_path):
+    """A transport that cannot be created ends its rank process right there -- exit code 1, the reason on stderr and in error.<rank>
+    for the other ranks' supervisors -- instead of unwinding through an interpreter teardown that may wait for a thread still
+    inside RCCL (launch.make_transport)."""
+    prog = ("import sys; sys.path.insert(0, %r)\n"
+            "from flowdenoising_amd import launch, _lib\n"
+            "_lib.device_count = lambda: 2\n"                              # (no GPU needed: the shared-memory kind with no peer)
+            "launch.make_transport(0, 2, 0, %r, kind='shm')\n"
+            "print('still here')\n") % (ROOT, str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", prog], env=dict(os.environ, FDN_RDV_TIMEOUT="2"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "still here" not in r.stdout, (r.returncode, r.stdout, r.stderr[-500:])
+    assert "rank 0" in r.stderr
+    # (without a GPU the reason is hipSetDevice's; on a GPU box the peer that never arrives)
+    assert (tmp_path / "error.0").read_text().startswith("FlowdnError:")
