@@ -7,6 +7,9 @@ spec = importlib.util.spec_from_file_location("tp", "tests/test_gpu_parity.py");
 import flowdenoising_amd as fdn
 from oracle import oracle
 oracle.build()
+import os        # the product reads these at handle creation (opencv_fma, remap_model): the oracle follows the same switches
+oracle.set_fma(int(os.environ.get("FDN_OPENCV_FMA", 0)), int(os.environ.get("FDN_OPENCV_FMA_LANES", 8)))
+oracle.set_remap_model(int(os.environ.get("FDN_REMAP_MODEL", 0)))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 bad = 0; exact = 0; order = 0
 cases = tp._random_cases(n, int(sys.argv[2]) if len(sys.argv) > 2 else 777)

@@ -8,6 +8,9 @@ import flowdenoising_amd as fdn
 from flowdenoising_amd.synth import make_volume
 from oracle import oracle
 oracle.build()
+import os        # the product reads these at handle creation (opencv_fma, remap_model): the oracle follows the same switches
+oracle.set_fma(int(os.environ.get("FDN_OPENCV_FMA", 0)), int(os.environ.get("FDN_OPENCV_FMA_LANES", 8)))
+oracle.set_remap_model(int(os.environ.get("FDN_REMAP_MODEL", 0)))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 31)
 bad = 0
