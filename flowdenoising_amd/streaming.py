@@ -234,6 +234,7 @@ def _passes(src, kernels, plan, mean, wrap, params, pool, worker_handle, timing=
     was_locked = [False, False]
 
     failed = []
+    abort = threading.Event()
 
     final_slot = (npasses - 1) & 1     # the array the last pass writes is the caller's result: always a fresh one
     kept_key = (worker_handle.device, tuple(src.shape))
@@ -292,9 +293,14 @@ def _passes(src, kernels, plan, mean, wrap, params, pool, worker_handle, timing=
                 return results[slot]
 
             def chunk_job(s0, s1, cur=cur, out_array=out_array, axis=axis, k=k, r=r, n=n, H=H, W=W, HW=HW, Z=Z, Y=Y, X=X, step=step):
+                if abort.is_set():                        # a chunk has failed: the ones still queued do nothing
+                    return
                 h, dev, give_back = worker_handle()
                 try:
                     _chunk(h, dev, s0, s1, cur, out_array, axis, k, r, n, H, W, HW, Z, Y, X, step)
+                except BaseException:
+                    abort.set()
+                    raise
                 finally:
                     give_back()
 
@@ -342,7 +348,19 @@ def _passes(src, kernels, plan, mean, wrap, params, pool, worker_handle, timing=
                 else:                                     # (S, Z, Y) -> (Z, Y, S) -> out[:, :, s0:s1]
                     h.permute_dev(d_out, d_blk, (H, W, S), (W, 1, H * W))
                     h.d2h_2d(obase + s0 * 4, X * 4, d_blk, S * 4, S * 4, Z * Y)
-            list(pool.map(lambda se: chunk_job(*se), [(s0, min(n, s0 + step)) for s0 in range(0, n, step)]))
+            futs = [pool.submit(chunk_job, s0, min(n, s0 + step)) for s0 in range(0, n, step)]
+            try:
+                for f in futs:
+                    f.result()
+            except BaseException:
+                # a chunk failed: the ones in flight still copy to and from the page-locked arrays -- they end before those
+                # arrays are released below; the ones that have not started never do (`abort`)
+                abort.set()
+                for f in futs:
+                    f.cancel()
+                from concurrent.futures import wait
+                wait(futs)
+                raise
             cur = out_array()
             if timing is not None:
                 timing[f"pass_{axis}_s"] = time.perf_counter() - t0

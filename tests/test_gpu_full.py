@@ -698,6 +698,42 @@ def test_streamed_filter_equals_resident_filter(fdn, tmp_path, l, border, chunk)
 
 
 @pytest.mark.gpu_subprocess
+def test_streamed_filter_survives_a_failing_chunk(fdn, tmp_path):
+    """A chunk that fails ends the call with its error only after the chunks in flight have ended (they copy to and from
+    page-locked arrays that the call then releases), chunks not yet started never run -- and the kept workers serve the next
+    call, bit-identical to the resident filter."""
+    from conftest import run_in_fresh_process
+    vol = _vol((14, 70, 90), seed=23)
+    ks = [fdn.get_gaussian_kernel(1.0), fdn.get_gaussian_kernel(0.5), fdn.get_gaussian_kernel(1.0)]
+    want = fdn.OF_filter(vol, ks, 0, 5)
+    code = ("import threading\n"
+            "from flowdenoising_amd import streaming, _lib\n"
+            "ks = [k0, k1, k2]\n"
+            "real = _lib.Handle.sweep_stack_dev\n"
+            "calls = []; lock = threading.Lock()\n"
+            "def flaky(self, *a, **kw):\n"
+            "    with lock:\n"
+            "        calls.append(1); n = len(calls)\n"
+            "    if n == 3:\n"
+            "        raise _lib.FlowdnError('injected: chunk 3 fails')\n"
+            "    return real(self, *a, **kw)\n"
+            "_lib.Handle.sweep_stack_dev = flaky\n"
+            "try:\n"
+            "    streaming.OF_filter_streamed(vol, ks, 0, 5, 2)\n"
+            "    out['raised'] = np.zeros(1)\n"
+            "except _lib.FlowdnError as e:\n"
+            "    out['raised'] = np.ones(1) * ('injected' in str(e))\n"
+            "out['calls_first'] = np.array([len(calls)])\n"
+            "_lib.Handle.sweep_stack_dev = real\n"
+            "out['of'] = streaming.OF_filter_streamed(vol, ks, 0, 5, 2)\n"
+            "streaming.release_workers()\n")
+    got, _ = run_in_fresh_process(code, dict(vol=vol, k0=ks[0], k1=ks[1], k2=ks[2]), tmp_path)
+    assert got["raised"][0] == 1
+    assert 3 <= int(got["calls_first"][0]) <= 5               # the failing chunk and at most the two in flight beside it (three workers): the Z pass has 7, Y and X never start
+    assert np.array_equal(got["of"], want)
+
+
+@pytest.mark.gpu_subprocess
 def test_strict_order_mode_reproduces_opencvs_horizontal_running_sum(oracle, tmp_path):
     """The fast kernels sum the box filter's horizontal window directly; OpenCV runs a serial f64 chain along
     the row.  In one of 7 080 random configurations that 1e-16 difference flipped an f32 rounding (5.8e-5 in
