@@ -315,6 +315,7 @@ class Handle:
         self._h = ctypes.c_void_p()
         check(self._lib.fdn_create(ctypes.c_int(device), ctypes.byref(self._h)))
         self.device = device
+        self.options = {}          # what set_option has been given (operators' pair-handle pool copies it to its extra handles)
 
     def close(self):
         if self._h:
@@ -356,6 +357,7 @@ class Handle:
     def set_option(self, name, value):
         """fdn_set_option: "strict_order", "path", "fused_occ", "lds_pad", "shard_loopback", "sub_batches" (see include/flowdn.h)."""
         check(self._lib.fdn_set_option(self._h, ctypes.c_char_p(name.encode()), ctypes.c_long(int(value))))
+        self.options = dict(self.options, **{name: int(value)})        # (a new dict: readers on other threads see old or new, whole)
 
     def get_option(self, name):
         """fdn_get_option: an option's value; also "last_sub_batches" and "compute_units" (read-only)."""

@@ -47,6 +47,88 @@ def handle(device=0):
         return h
 
 
+# The pair operators' handles.  par calls get_flow / warp_slice from its P pool threads at once (par:187-193, par:306-327).
+# One handle serves them correctly -- every entry point takes the handle's lock -- but one after another, and one pair of
+# images fills a twelfth of the GPU for the 1.5 ms a workgroup needs to march down 1024 rows.  So concurrent callers each take
+# a handle (its own stream, workspaces and bounce buffer) from a small pool: the first is the process-wide handle (a
+# single-threaded caller never sees another), more are made when a call finds every handle in use, up to FDN_PAIR_HANDLES
+# (default 8); beyond that callers wait for a free one.
+class _PairHandles:
+    def __init__(self, device):
+        import os
+        import queue
+        self.device = device
+        self.free = queue.LifoQueue()          # last in, first out: a lone caller keeps getting the same handle
+        self.made = 0
+        self.limit = max(1, int(os.environ.get("FDN_PAIR_HANDLES", "8")))
+        self.lock = threading.Lock()
+        self.extra = []
+
+    def take(self):
+        h = self._take()
+        main = _handles.get(self.device)
+        if main is not None and h is not main and h.options != main.options:
+            # what the caller has set on the process-wide handle (strict_order, opencv_fma, remap_model ...) holds for the
+            # pair operators whichever handle serves them
+            try:
+                for k, v in main.options.items():
+                    if h.options.get(k) != v:
+                        h.set_option(k, v)
+            except BaseException:
+                self.free.put(h)
+                raise
+        return h
+
+    def _take(self):
+        import queue
+        try:
+            return self.free.get_nowait()
+        except queue.Empty:
+            pass
+        with self.lock:
+            make = self.made < self.limit
+            first = self.made == 0
+            if make:
+                self.made += 1
+        if not make:
+            return self.free.get()
+        try:
+            if first:
+                return handle(self.device)
+            h = _lib.Handle(self.device)
+            with self.lock:
+                self.extra.append(h)
+            return h
+        except BaseException:
+            with self.lock:
+                self.made -= 1
+            raise
+
+    def give_back(self, h):
+        self.free.put(h)
+
+
+_pair_pools = {}
+
+
+def _pair_pool(device):
+    with _handles_lock:
+        pool = _pair_pools.get(device)
+        if pool is None:
+            pool = _pair_pools[device] = _PairHandles(device)
+        return pool
+
+
+def release_pair_handles():
+    """Close the extra handles the pair operators made for concurrent callers (the process-wide handle stays)."""
+    with _handles_lock:
+        pools = list(_pair_pools.values())
+        _pair_pools.clear()
+    for pool in pools:
+        for h in pool.extra:
+            h.close()
+
+
 def _params(l, w, use_of=True, border_mode=_lib.BORDER_MEAN_PAD, chained=True):
     return _lib.SweepParams(int(l), int(w), OF_ITERS, OF_POLY_N, OF_POLY_SIGMA, int(border_mode),
                             int(bool(chained)), int(bool(use_of)))
@@ -61,8 +143,12 @@ def get_flow(reference, target, l=OF_LEVELS, w=OF_WINDOW_SIZE, prev_flow=None, d
     OPTFLOW_USE_INITIAL_FLOW): `prev_flow` is the initial guess and is overwritten in place."""
     if prev_flow is None:
         raise ValueError("OPTFLOW_USE_INITIAL_FLOW needs prev_flow (cv2 asserts the same)")
-    return handle(device).farneback(target, reference, prev_flow, l, w, OF_ITERS, OF_POLY_N, OF_POLY_SIGMA,
-                                    _lib.USE_INITIAL_FLOW)
+    pool = _pair_pool(device)
+    h = pool.take()
+    try:
+        return h.farneback(target, reference, prev_flow, l, w, OF_ITERS, OF_POLY_N, OF_POLY_SIGMA, _lib.USE_INITIAL_FLOW)
+    finally:
+        pool.give_back(h)
 
 
 get_flow_with_prev_flow = get_flow  # par:65
@@ -70,11 +156,21 @@ get_flow_with_prev_flow = get_flow  # par:65
 
 def get_flow_without_prev_flow(reference, target, l=OF_LEVELS, w=OF_WINDOW_SIZE, prev_flow=None, device=0):
     """par:89-114: flags=0, flow=None."""
-    return handle(device).farneback(target, reference, None, l, w, OF_ITERS, OF_POLY_N, OF_POLY_SIGMA, 0)
+    pool = _pair_pool(device)
+    h = pool.take()
+    try:
+        return h.farneback(target, reference, None, l, w, OF_ITERS, OF_POLY_N, OF_POLY_SIGMA, 0)
+    finally:
+        pool.give_back(h)
 
 
 def warp_slice(reference, flow, device=0):
-    return handle(device).warp(reference, flow)
+    pool = _pair_pool(device)
+    h = pool.take()
+    try:
+        return h.warp(reference, flow)
+    finally:
+        pool.give_back(h)
 
 
 def _filter_axis(vol, axis, kernel, l, w, mean, use_of, border_mode, chained, device):

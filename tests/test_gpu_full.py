@@ -104,13 +104,78 @@ def test_flowdenoising_class_mirrors_par(fdn, oracle):
 
 
 @pytest.mark.gpu_subprocess
+def test_pair_operators_on_one_shared_handle(fdn, tmp_path):
+    """FDN_PAIR_HANDLES=1: every pool thread's get_flow / warp_slice goes through the ONE process-wide handle; the C ABI's
+    lock per handle serialises them: eight threads = one thread, bit for bit."""
+    from conftest import run_in_fresh_process
+    vol = _vol((17, 40, 83), seed=24)
+    ks = [fdn.get_gaussian_kernel(1.0), None, fdn.get_gaussian_kernel(0.5)]
+    code = (
+        "import flowdenoising_amd as fdn, _par_pool\n"
+        "from flowdenoising_amd import operators\n"
+        "ks = [k0, None, k2]\n"
+        "out['pool'] = _par_pool.par_sweep(fdn.get_flow_with_prev_flow, fdn.warp_slice, vol, ks, 0, 5, 8)\n"
+        "out['single'] = _par_pool.par_sweep(fdn.get_flow_with_prev_flow, fdn.warp_slice, vol, ks, 0, 5, 1)\n"
+        "out['made'] = np.array([operators._pair_pool(0).made])\n")
+    got, _ = run_in_fresh_process(code, {"vol": vol, "k0": ks[0], "k2": ks[2]}, tmp_path, env={"FDN_PAIR_HANDLES": "1"})
+    assert got["made"][0] == 1
+    assert np.array_equal(got["pool"], got["single"])
+
+
+@pytest.mark.gpu_subprocess
+def test_pair_handle_pool_follows_the_options_of_the_process_wide_handle(fdn, oracle, tmp_path):
+    """What a caller sets on the process-wide handle (here remap_model = 1 and opencv_fma = 1 with a pyramid) holds for the
+    pair operators whichever pool handle serves a thread -- also when it is changed after the pool's handles exist."""
+    from conftest import run_in_fresh_process
+    import _par_pool
+    vol = _vol((9, 70, 90), seed=25)
+    ks = [fdn.get_gaussian_kernel(0.5), None, None]
+    code = (
+        "import flowdenoising_amd as fdn, _par_pool\n"
+        "from flowdenoising_amd import operators\n"
+        "ks = [k0, None, None]\n"
+        "out['default_pool'] = _par_pool.par_sweep(fdn.get_flow_with_prev_flow, fdn.warp_slice, vol, ks, 2, 5, 4)\n"
+        "out['made'] = np.array([operators._pair_pool(0).made])\n"
+        "operators.handle().set_option('remap_model', 1)\n"
+        "operators.handle().set_option('opencv_fma', 1)\n"
+        "out['pool'] = _par_pool.par_sweep(fdn.get_flow_with_prev_flow, fdn.warp_slice, vol, ks, 2, 5, 4)\n"
+        "out['single'] = _par_pool.par_sweep(fdn.get_flow_with_prev_flow, fdn.warp_slice, vol, ks, 2, 5, 1)\n"
+        "operators.release_pair_handles()\n")
+    got, _ = run_in_fresh_process(code, {"vol": vol, "k0": ks[0]}, tmp_path)
+    assert got["made"][0] >= 2, "the pool never made a second handle: the test did not test it"
+    assert np.array_equal(got["pool"], got["single"])
+    assert not np.array_equal(got["pool"], got["default_pool"])
+
+    def o_warp(reference, flow):
+        H, W = flow.shape[:2]
+        m = np.empty((H, W, 2), np.float32)
+        m[..., 0] = (flow[..., 0].astype(np.float64) + np.arange(W)[None, :]).astype(np.float32)
+        m[..., 1] = (flow[..., 1].astype(np.float64) + np.arange(H)[:, None]).astype(np.float32)
+        return oracle.remap_any(np.ascontiguousarray(reference), m)
+
+    def o_flow(reference, target, l, w, prev_flow):
+        return oracle.get_flow(np.asarray(reference, np.float32), np.asarray(target, np.float32), l, w, prev_flow)
+
+    oracle.set_remap_model(1)
+    oracle.set_fma(1)
+    try:
+        want = _par_pool.par_sweep(o_flow, o_warp, vol, ks, 2, 5, 1)
+    finally:
+        oracle.set_remap_model(0)
+        oracle.set_fma(0)
+    assert np.array_equal(got["pool"], want)
+
+
+@pytest.mark.gpu_subprocess
 @pytest.mark.parametrize("dtype", [np.float32, np.int16])
 def test_pair_operators_under_pars_thread_pool(fdn, oracle, tmp_path, dtype):
     """The seam par injects into (`FlowDenoising(P, vol, l, w, get_flow, warp_slice)`, par:506) as par itself uses it:
     P = 8 pool threads call get_flow / warp_slice at once on views of one shared volume (par:187-193, 299-327;
-    tests/_par_pool.py restates the scheduler and the slice loops).  All of them go through the ONE process-wide handle
-    behind `flowdenoising_amd.get_flow_with_prev_flow` / `warp_slice`; the C ABI serialises them (a lock per handle), so
-    the eight-thread result must be the single-thread one bit for bit -- and both the oracle's for the same loops.
+    tests/_par_pool.py restates the scheduler and the slice loops).  Concurrent callers of
+    `flowdenoising_amd.get_flow_with_prev_flow` / `warp_slice` each take a handle from the operators' small pool (the
+    process-wide handle first; FDN_PAIR_HANDLES = 1 puts them all on that one, which the C ABI serialises with its lock
+    per handle -- test_pair_operators_on_one_shared_handle); the eight-thread result must be the single-thread one bit
+    for bit -- and both the oracle's for the same loops.
     Axis lengths 17 / 66 / 83 leave a remainder round on every pass.  Runs in a process of its own (conftest)."""
     from conftest import run_in_fresh_process
     import _par_pool
